@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Benchmark of the SPH step path: particle-steps/s of the `-m time` loop
+(main.cpp:68-76: N x simulateAndTime from the reference initial condition) plus
+the computeDensity roofline figures and the CPU-oracle baseline.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one simulateAndTime(): grid build + density + force/integrate +
+position read-back.  Warm-up steps run first, then the initial condition is
+re-uploaded so the K timed steps are steps 1..K of the reference's run (work per
+step grows as the fluid settles).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANEOPS = 7.86e13    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+DENSITY_BYTES_PER_PARTICLE = 20  # read 12-B position, write rho + p
+DENSITY_LANEOPS_PER_TEST = 12    # SURVEY.md 8d convention
+FORCE_LANEOPS_PER_TEST = 55
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("-n", "--particles", type=int, default=4194304,
+                    help="BASELINE.json configs[2]: -n 4194304 -i random -m time")
+    ap.add_argument("--init", choices=["random", "grid"], default="random")
+    ap.add_argument("--sweep", choices=["lds", "direct"], default="lds")
+    ap.add_argument("--mode", choices=["time", "free"], default="time",
+                    help="time: simulateAndTime loop (-m time); free: simulate() loop")
+    ap.add_argument("--cpu-steps", type=int, default=4,
+                    help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-particles", type=int, default=0, help="0 = same n as the GPU run")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, random_init, steps):
+    """The CPU oracle (kind 'port': the reference has no CPU path and its CUDA
+    source cannot be built here) on the host's cores, bounded sample."""
+    from oracle import oracle as O
+    sim = O.OracleSim(n, random_init)
+    sim.setup()
+    t0 = time.perf_counter()
+    sim.step(steps)
+    dt = time.perf_counter() - t0
+    sim.close()
+    return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(),
+            "kind": "port",
+            "sample": f"first {steps} steps of -n {n} -i {'random' if random_init else 'grid'} "
+                      f"(of the 100-step run; later steps cost up to 4.7x more), "
+                      f"OpenMP oracle, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N>1 must be launched through torch.distributed.run")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback); use -m 'not gpu' tests on CPU")
+
+    import cudafluidsimulator_amd as sph
+    from cudafluidsimulator_amd import _lib
+
+    n = args.particles
+    random_init = args.init == "random"
+    K, W = args.steps, args.warmup
+
+    if world > 1:
+        from cudafluidsimulator_amd.slab import run_slab_bench
+        result = run_slab_bench(args, dist, rank, world, local_rank)
+    else:
+        s = sph.default_settings(n, random_init)
+        sim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank)
+        sim.setup()
+        times = sph.Times()
+        for _ in range(W):
+            sim.simulateAndTime(times) if args.mode == "time" else sim.simulate()
+        sim.sync()
+        sim.setup()  # back to the initial condition: timed steps are steps 1..K
+        sim.kernel_times(reset=True)
+        times = sph.Times()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if args.mode == "time":
+            for _ in range(K):
+                sim.simulateAndTime(times)
+        else:
+            for _ in range(K):
+                sim.simulate()
+        sim.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kt = sim.kernel_times()
+        result = dict(elapsed=elapsed, kt=kt, times=times, n_total=n)
+        sim.close()
+
+    if world > 1:
+        t = torch.tensor([result["elapsed"]], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        result["elapsed"] = float(t.item())
+
+    if rank == 0:
+        elapsed = result["elapsed"]
+        kt = result["kt"]
+        steps = max(int(kt.steps), 1)
+        dens_s = kt.density / steps      # avg launch duration of computeDensity (HIP events)
+        force_s = kt.force / steps
+        n_local = result.get("n_local", n)
+        pairs = kt.pair_tests / steps if kt.pair_tests else None
+        achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_density_lds (computeDensity)" if args.sweep == "lds"
+                else "k_density_direct", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": dens_s * 1e6,
+                "algorithmic_bytes_per_launch": DENSITY_BYTES_PER_PARTICLE * n_local,
+                "note": "the sweep is VALU-bound, not HBM-bound (SURVEY.md 8d): see valu_frac"}
+        if pairs:
+            roof["pair_tests_per_launch"] = pairs
+            roof["valu_frac"] = pairs * DENSITY_LANEOPS_PER_TEST / dens_s / VALU_PEAK_LANEOPS
+            roof["force_valu_frac"] = pairs * FORCE_LANEOPS_PER_TEST / force_s / VALU_PEAK_LANEOPS
+        out = {
+            "metric": "particle-steps/sec (100-step -m time)",
+            "value": result["n_total"] * K / elapsed,
+            "unit": "particle-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"-n {result['n_total']} -i {args.init} -m {args.mode}, "
+                                   f"{world}xMI355X, flattened-index radix sort + float4 SoA, "
+                                   f"strict fp32 (bit-identical to the CPU oracle)",
+                       "sweep": args.sweep,
+                       "parallelism": "single domain" if world == 1 else f"z-slabs x{world} + RCCL halo"},
+            "roofline": roof,
+            "kernel_ms_per_step": {"hash": kt.hash / steps * 1e3, "sort": kt.sort / steps * 1e3,
+                                   "gather_cells": kt.gather / steps * 1e3,
+                                   "density": dens_s * 1e3, "force_integrate": force_s * 1e3,
+                                   "readback_d2h": kt.readback / steps * 1e3},
+        }
+        if "times" in result:
+            t = result["times"]
+            out["m_time_table_s"] = {"grid_construction": t.buildGrid, "sph_update": t.sphUpdate,
+                                     "data_transfer_exposed": t.memcpy}
+        if args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_particles or n, random_init, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

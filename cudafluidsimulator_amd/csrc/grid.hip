@@ -1,0 +1,119 @@
+// Neighbour-grid build around the radix sort: particle -> cell hash, and the
+// fused "apply permutation + detect cell boundaries" pass that replaces the
+// reference's per-cell linked-list heads (simulator.cu:133-147) with a
+// {start,end} range per flattened cell over the key-sorted particle streams.
+// Also the click impulse (kernelMoveParticles, simulator.cu:329-367).
+#include "sph_device.h"
+
+// getGridCell + flattenGridCoord (simulator.cu:57-82).  The division is the
+// IEEE fp32 divide of the reference (hipcc's default `/` is correctly rounded);
+// the flattening is done in integers, which equals the reference's float
+// evaluation exactly below 2^24.  Cells are clamped into the table so a
+// position outside the box can never index out of bounds (the reference only
+// printf's in that case, simulator.cu:60-73).
+__device__ __forceinline__ int3 grid_cell(const DevParams &P, float x, float y,
+                                          float z) {
+    int3 c;
+    c.x = (int)(x / P.h);
+    c.y = (int)(y / P.h);
+    c.z = (int)(z / P.h);
+    c.x = min(max(c.x, 0), P.D - 1);
+    c.y = min(max(c.y, 0), P.D - 1);
+    c.z = min(max(c.z, 0), P.D - 1);
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_hash(DevParams P,
+                                              const float4 *__restrict__ pos4,
+                                              uint32_t *__restrict__ keys,
+                                              uint32_t *__restrict__ vals, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos4[i];
+    int3 c = grid_cell(P, p.x, p.y, p.z);
+    keys[i] = (uint32_t)(c.x + c.y * P.D + c.z * P.D * P.D);
+    vals[i] = (uint32_t)i;
+}
+
+void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
+                     uint32_t *vals, int n, hipStream_t s) {
+    if (n <= 0) return;
+    k_hash<<<(n + 255) / 256, 256, 0, s>>>(P, pos4, keys, vals, n);
+}
+
+// One pass over the sorted (key, source slot) pairs: move both float4 streams
+// into sorted order (16-B gathers, 16-B coalesced stores) and write cell
+// boundaries.  A lane compares its key with its wave neighbours through DPP
+// shuffles; only lanes 0 and 63 touch memory for the key next door.
+// cellRange must have been cleared (hipMemsetAsync) beforehand: empty cells
+// keep {0,0}.
+__global__ __launch_bounds__(256) void k_gather_cells(
+    const float4 *__restrict__ pos_in, const float4 *__restrict__ vel_in,
+    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ skeys,
+    float4 *__restrict__ pos_out, float4 *__restrict__ vel_out,
+    int2 *__restrict__ cellRange, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool valid = i < n;
+    uint32_t k = valid ? skeys[i] : 0xFFFFFFFFu;
+    uint32_t kprev = __shfl_up(k, 1);
+    uint32_t knext = __shfl_down(k, 1);
+    if (lane == 0) kprev = (valid && i > 0) ? skeys[i - 1] : 0xFFFFFFFFu;
+    if (lane == 63) knext = (i + 1 < n) ? skeys[i + 1] : 0xFFFFFFFFu;
+    if (!valid) return;
+    if (i + 1 >= n) knext = 0xFFFFFFFFu;
+    uint32_t src = perm[i];
+    pos_out[i] = pos_in[src];
+    vel_out[i] = vel_in[src];
+    if (k != kprev) cellRange[k].x = i;
+    if (k != knext) cellRange[k].y = i + 1;
+}
+
+void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
+                       const uint32_t *perm, const uint32_t *sorted_keys,
+                       float4 *pos_out, float4 *vel_out, int2 *cellRange, int n,
+                       hipStream_t s) {
+    if (n <= 0) return;
+    k_gather_cells<<<(n + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, sorted_keys,
+                                                   pos_out, vel_out, cellRange, n);
+}
+
+// kernelMoveParticles (simulator.cu:329-367), launched <<<1, numCellsPerDim>>>
+// like the reference (simulator.cu:483-486): thread t owns z-layer
+// (int)((float)t*h/h).  Velocities are edited in the sorted stream through the
+// cell table of the last grid build (the reference also uses the
+// pre-integration grid here).
+__global__ void k_click(DevParams P, const int2 *__restrict__ cellRange,
+                        float4 *__restrict__ vel4, int mx, int my) {
+    float x = ((float)(mx - SPH_BOX_MIN_X) / (float)(SPH_BOX_MAX_X - SPH_BOX_MIN_X)) *
+              P.boxDim;
+    float y = ((float)(my - SPH_BOX_MIN_Y) / (float)(SPH_BOX_MAX_Y - SPH_BOX_MIN_Y)) *
+              P.boxDim;
+    float z = (float)threadIdx.x * P.h;
+    int cx = (int)(x / P.h);
+    int cy = (int)(y / P.h);
+    int cz = (int)(z / P.h);
+    cy = (int)((float)P.D - (float)cy);
+    if (cz < 0 || cz >= P.D) return;
+    for (int dy = -2; dy < 3; dy++) {
+        int sy = cy + dy;
+        if (sy < 0 || sy >= P.D) continue;
+        for (int dx = -2; dx < 3; dx++) {
+            int sx = cx + dx;
+            if (sx < 0 || sx >= P.D) continue;
+            int2 r = cellRange[sx + sy * P.D + cz * P.D * P.D];
+            for (int j = r.x; j < r.y; j++) {
+                float4 v = vel4[j];
+                if (dx != 0) v.x += (1.f / dx) * SPH_PUSH_STRENGTH;
+                if (dy != 0) v.y += (1.f / dy) * SPH_PUSH_STRENGTH;
+                if (dx == 0 && dy == 0) v.z -= SPH_PUSH_STRENGTH;
+                vel4[j] = v;
+            }
+        }
+    }
+}
+
+void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4, int mx,
+                      int my, hipStream_t s) {
+    k_click<<<1, P.D, 0, s>>>(P, cellRange, vel4, mx, my);
+}

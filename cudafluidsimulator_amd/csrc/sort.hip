@@ -1,0 +1,183 @@
+// Stable LSD radix sort of (cell key, particle slot) pairs -- the sort-based
+// replacement for the reference's lock-free linked-list grid build
+// (kernelBuildGrid + insertList, simulator.cu:44-55,133-147).  Written for
+// gfx950: 8-bit digits, one 4096-key tile per 256-thread workgroup, each of the
+// four 64-lane waves owns a CONTIGUOUS 1024-key chunk so that (wave, round,
+// lane) order is index order and ranks are stable.  Equal digits inside a wave
+// are found with 8 wave-wide ballots (a 64-bit match mask), the prefix popcount
+// of that mask is the in-wave rank -- no per-key LDS atomics, no serialisation
+// when a whole tile shares one digit (the usual case for the top digit of an
+// almost-sorted key stream).
+//
+// Per pass: k_radix_hist (tile histograms, digit-major) -> k_radix_rowscan
+// (one workgroup per digit scans its row of tile counts) -> k_radix_scatter
+// (re-rank in the tile, add digit base + tile base, scatter).
+// HBM traffic per pass: read 4 B (hist) + read 8 B + write 8 B per pair.
+#include "sph_device.h"
+
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_WAVES (RS_THREADS / SPH_WAVE)
+#define RS_WAVE_TILE (SPH_WAVE * RS_ITEMS)
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+
+// Lanes of this wave whose digit equals mine (among valid lanes).
+__device__ __forceinline__ unsigned long long match_digit(uint32_t digit,
+                                                          bool valid) {
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        bool bit = (digit >> b) & 1u;
+        unsigned long long v = __ballot(valid && bit);
+        m &= bit ? v : ~v;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    // popcount of m restricted to lanes lower than mine
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
+    const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
+    int shift, int numBlocks) {
+    __shared__ uint32_t hist[256];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    hist[t] = 0;
+    __syncthreads();
+    const long long base =
+        (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_TILE + lane;
+#pragma unroll 4
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        long long idx = base + r * SPH_WAVE;
+        bool valid = idx < n;
+        uint32_t key = valid ? keys[idx] : 0u;
+        uint32_t d = (key >> shift) & 255u;
+        unsigned long long m = match_digit(d, valid);
+        if (valid && lanes_below(m) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    blockHist[(size_t)t * numBlocks + blockIdx.x] = hist[t];
+}
+
+// Block-wide inclusive scan of one value per thread (256 threads).
+__device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v,
+                                                             uint32_t *tmp) {
+    const int t = threadIdx.x;
+    tmp[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < RS_THREADS; off <<= 1) {
+        uint32_t add = (t >= off) ? tmp[t - off] : 0u;
+        __syncthreads();
+        tmp[t] += add;
+        __syncthreads();
+    }
+    return tmp[t];
+}
+
+// grid = 256 workgroups (one per digit); exclusive scan of that digit's row of
+// tile counts, in place, and the digit's total.
+__global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(
+    uint32_t *__restrict__ blockHist, uint32_t *__restrict__ digitTotal,
+    int numBlocks) {
+    __shared__ uint32_t tmp[RS_THREADS];
+    uint32_t *row = blockHist + (size_t)blockIdx.x * numBlocks;
+    const int t = threadIdx.x;
+    const int chunk = (numBlocks + RS_THREADS - 1) / RS_THREADS;
+    const int b0 = min(t * chunk, numBlocks), b1 = min(b0 + chunk, numBlocks);
+    uint32_t s = 0;
+    for (int b = b0; b < b1; ++b) s += row[b];
+    uint32_t incl = block_inclusive_scan_256(s, tmp);
+    if (t == RS_THREADS - 1) digitTotal[blockIdx.x] = incl;
+    uint32_t run = incl - s;
+    for (int b = b0; b < b1; ++b) {
+        uint32_t c = row[b];
+        row[b] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
+    const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
+    uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut,
+    const uint32_t *__restrict__ blockHist,
+    const uint32_t *__restrict__ digitTotal, int n, int shift, int numBlocks) {
+    __shared__ uint32_t waveCount[RS_WAVES][256];
+    __shared__ uint32_t digitOff[256];
+    __shared__ uint32_t tmp[RS_THREADS];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int q = 0; q < RS_WAVES; ++q) waveCount[q][t] = 0;
+    // global base of digit t for this tile = (sum of totals of smaller digits)
+    // + (count of digit t in earlier tiles)
+    uint32_t tot = digitTotal[t];
+    uint32_t incl = block_inclusive_scan_256(tot, tmp); // ends with a barrier
+    uint32_t myBase = (incl - tot) + blockHist[(size_t)t * numBlocks + blockIdx.x];
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    const long long base =
+        (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_TILE + lane;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        long long idx = base + r * SPH_WAVE;
+        bool valid = idx < n;
+        key[r] = valid ? keysIn[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? valsIn[idx] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        long long idx = base + r * SPH_WAVE;
+        bool valid = idx < n;
+        uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long m = match_digit(d, valid);
+        uint32_t below = lanes_below(m);
+        uint32_t old = waveCount[w][d]; // every lane reads before the leader adds
+        rank[r] = old + below;
+        if (valid && below == 0) waveCount[w][d] = old + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        uint32_t c0 = waveCount[0][t], c1 = waveCount[1][t], c2 = waveCount[2][t];
+        waveCount[0][t] = 0;
+        waveCount[1][t] = c0;
+        waveCount[2][t] = c0 + c1;
+        waveCount[3][t] = c0 + c1 + c2;
+        digitOff[t] = myBase;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        long long idx = base + r * SPH_WAVE;
+        if (idx < n) {
+            uint32_t d = (key[r] >> shift) & 255u;
+            uint32_t dst = digitOff[d] + waveCount[w][d] + rank[r];
+            keysOut[dst] = key[r];
+            valsOut[dst] = val[r];
+        }
+    }
+}
+
+size_t sph_sort_workspace_blocks(int n) {
+    return (size_t)((n + RS_TILE - 1) / RS_TILE);
+}
+
+int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s) {
+    if (n <= 0) return 0;
+    const int numBlocks = (n + RS_TILE - 1) / RS_TILE;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        k_radix_hist<<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n,
+                                                      shift, numBlocks);
+        k_radix_rowscan<<<256, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal,
+                                                   numBlocks);
+        k_radix_scatter<<<numBlocks, RS_THREADS, 0, s>>>(
+            ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1],
+            ws.blockHist, ws.digitTotal, n, shift, numBlocks);
+        cur ^= 1;
+    }
+    return cur;
+}

@@ -1,0 +1,707 @@
+// C-ABI implementation (include/sph_c_api.h) of the MI355X SPH step path.
+// Host logic only; the kernels live in sort.hip / grid.hip / sweeps.hip.
+//
+// Step pipeline (replaces Simulator::simulate / simulateAndTime,
+// simulator.cu:462-546):
+//   compute stream: clear cell table -> hash -> 3-pass radix sort -> gather +
+//                   cell ranges -> density -> force+integrate (+ scatter of
+//                   positions into original-id order)
+//   copy stream:    D2H of the id-ordered positions into pinned host memory,
+//                   double-buffered on the device so step k+1 computes while
+//                   step k's positions cross PCIe (the reference blocks on this
+//                   copy every step, simulator.cu:479-480,532-533).
+// Compile with -ffp-contract=off (host initialisers must round like the
+// reference's g++ -O3 x86-64 build, Makefile:22-23).
+#include "sph_c_api.h"
+#include "sph_device.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int kEventRing = 64;
+
+struct StepEvents {
+    hipEvent_t e[6]; // start, hash, sort, gather, density, force
+    hipEvent_t c[2]; // copy start / end
+    bool used = false, hasCopy = false, counted = false;
+};
+
+} // namespace
+
+struct sph_handle {
+    SphSettings settings{};
+    SphOptions opt{};
+    DevParams P{};
+    int n = 0, cap = 0, device = 0;
+    hipStream_t compute = nullptr, copy = nullptr;
+    float4 *pos4[2] = {nullptr, nullptr};
+    float4 *vel4[2] = {nullptr, nullptr};
+    int cur = 0;     // buffers holding the current state
+    int sorted = -1; // buffers holding the sorted streams of the last grid build
+    SortWorkspace ws{};
+    int sortedKeyBuf = 0;
+    int2 *cellRange = nullptr;
+    float *devPos[2] = {nullptr, nullptr};
+    float *hostPos = nullptr; // pinned, n*3
+    hipEvent_t computeDone[2] = {nullptr, nullptr}, copyDone[2] = {nullptr, nullptr};
+    bool copyPending[2] = {false, false};
+    long long stepIndex = 0;
+    float4 *force4 = nullptr;
+    unsigned long long *pairCounter = nullptr; // device
+    unsigned long long *pairHost = nullptr;    // pinned
+    StepEvents ring[kEventRing];
+    int ringHead = 0;
+    StepEvents *curEv = nullptr;
+    SphKernelTimes kt{};
+    bool ready = false;     // state uploaded
+    bool gridValid = false; // sorted streams + cell table match `sorted`
+    int phase = 0;          // 0 idle, 1 grid done, 2 density done, 3 force done
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                               \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);            \
+            return SPH_EHIP;                                                          \
+        }                                                                             \
+    } while (0)
+
+int fail(sph_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+// Largest dist2 for which pressureKernel (dist2 <= h*h) or viscosityKernel
+// (sqrtf(dist2) <= h) can be non-zero (simulator.cu:105,125).
+float force_cut2(float h) {
+    float h2 = h * h;
+    float x = h2;
+    for (int k = 0; k < 64; ++k) {
+        float nx = std::nextafterf(x, INFINITY);
+        if (sqrtf(nx) <= h) x = nx;
+        else break;
+    }
+    return x;
+}
+
+void fill_params(sph_handle *h) {
+    const SphSettings &s = h->settings;
+    DevParams &P = h->P;
+    P.h = s.h;
+    P.h2 = s.h * s.h;
+    P.vcoef = s.v_kernel_coeff;
+    P.dcoef = s.d_kernel_coeff;
+    P.boxDim = s.boxDim;
+    P.boxHi = s.boxDim - s.h;
+    P.dt = s.timestep;
+    P.cut2 = force_cut2(s.h);
+    P.D = (int)s.numCellsPerDim;
+    P.numCells = P.D * P.D * P.D;
+}
+
+int key_bits(const sph_handle *h) {
+    int bits = 1;
+    while ((1ll << bits) < (long long)h->P.numCells) ++bits;
+    return bits;
+}
+
+// Simulator::setup's initialisers (simulator.cu:430-453).
+int init_positions_reference(const SphSettings &s, float *pos) {
+    int n = s.numParticles;
+    if (s.randomInit) {
+        srand(1); // the state of a process that never called srand (the reference)
+        for (int i = 0; i < n; i++) {
+            float x = rand() / (float)RAND_MAX * (s.boxDim - 2.f) + 1.f;
+            float y = rand() / (float)RAND_MAX * (s.boxDim - 2.f) + 1.f;
+            float z = rand() / (float)RAND_MAX * (s.boxDim - 2.f) + 1.f;
+            pos[3 * i + 0] = x;
+            pos[3 * i + 1] = y;
+            pos[3 * i + 2] = z;
+        }
+        return n;
+    }
+    float spacing = 0.9f * s.h;
+    int nx = (int)(floor((s.boxDim - 2 * s.h) / spacing) + 1);
+    int ny = nx, nz = nx;
+    int count = 0;
+    for (int x = 0; x < nx && count < n; x++)
+        for (int y = 0; y < ny && count < n; y++)
+            for (int z = 0; z < nz && count < n; z++) {
+                pos[3 * count + 0] = s.h + spacing * x;
+                pos[3 * count + 1] = s.h + spacing * y;
+                pos[3 * count + 2] = s.h + spacing * z;
+                count++;
+            }
+    return count;
+}
+
+// Extension for n beyond the reference lattice's 109^3 capacity.
+void init_positions_dense(const SphSettings &s, float *pos) {
+    int n = s.numParticles;
+    int nx = (int)ceil(cbrt((double)n));
+    while ((long long)nx * nx * nx < n) nx++;
+    while (nx > 1 && (long long)(nx - 1) * (nx - 1) * (nx - 1) >= n) nx--;
+    float spacing = nx > 1 ? (s.boxDim - 2 * s.h) / (float)(nx - 1) : 0.f;
+    int count = 0;
+    for (int x = 0; x < nx && count < n; x++)
+        for (int y = 0; y < nx && count < n; y++)
+            for (int z = 0; z < nx && count < n; z++) {
+                pos[3 * count + 0] = s.h + spacing * x;
+                pos[3 * count + 1] = s.h + spacing * y;
+                pos[3 * count + 2] = s.h + spacing * z;
+                count++;
+            }
+}
+
+int alloc_device(sph_handle *h) {
+    const size_t cap = (size_t)(h->cap > 0 ? h->cap : 1);
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(h, hipMalloc(&h->pos4[b], cap * sizeof(float4)));
+        HIPCHK(h, hipMalloc(&h->vel4[b], cap * sizeof(float4)));
+        HIPCHK(h, hipMalloc(&h->ws.keys[b], cap * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->ws.vals[b], cap * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->devPos[b], cap * 3 * sizeof(float)));
+        // never hand uninitialised indices to a gather, whatever happens upstream
+        HIPCHK(h, hipMemset(h->pos4[b], 0, cap * sizeof(float4)));
+        HIPCHK(h, hipMemset(h->vel4[b], 0, cap * sizeof(float4)));
+        HIPCHK(h, hipMemset(h->ws.keys[b], 0, cap * sizeof(uint32_t)));
+        HIPCHK(h, hipMemset(h->ws.vals[b], 0, cap * sizeof(uint32_t)));
+        HIPCHK(h, hipEventCreateWithFlags(&h->computeDone[b], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->copyDone[b], hipEventDisableTiming));
+    }
+    h->ws.capacity = (int)cap;
+    h->ws.maxBlocks = (int)sph_sort_workspace_blocks((int)cap);
+    HIPCHK(h, hipMalloc(&h->ws.blockHist,
+                        (size_t)256 * (size_t)(h->ws.maxBlocks > 0 ? h->ws.maxBlocks : 1) *
+                            sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->ws.digitTotal, 256 * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->cellRange, (size_t)h->P.numCells * sizeof(int2)));
+    HIPCHK(h, hipMemset(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2)));
+    HIPCHK(h, hipHostMalloc(&h->hostPos, cap * 3 * sizeof(float), hipHostMallocDefault));
+    memset(h->hostPos, 0, cap * 3 * sizeof(float));
+    if (h->opt.flags & SPH_FLAG_STORE_FORCE)
+        HIPCHK(h, hipMalloc(&h->force4, cap * sizeof(float4)));
+    HIPCHK(h, hipMalloc(&h->pairCounter, sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->pairCounter, 0, sizeof(unsigned long long)));
+    HIPCHK(h, hipHostMalloc(&h->pairHost, sizeof(unsigned long long), hipHostMallocDefault));
+    *h->pairHost = 0;
+    for (auto &se : h->ring) {
+        for (auto &e : se.e) HIPCHK(h, hipEventCreate(&e));
+        for (auto &e : se.c) HIPCHK(h, hipEventCreate(&e));
+    }
+    HIPCHK(h, hipDeviceSynchronize()); // memsets above ran on the null stream
+    return SPH_OK;
+}
+
+// Fold one finished step's events into the accumulated kernel times.
+int resolve_events(sph_handle *h, StepEvents &se) {
+    if (!se.used || se.counted) return SPH_OK;
+    HIPCHK(h, hipEventSynchronize(se.e[5]));
+    float ms[5];
+    for (int k = 0; k < 5; ++k) HIPCHK(h, hipEventElapsedTime(&ms[k], se.e[k], se.e[k + 1]));
+    h->kt.hash += ms[0] * 1e-3;
+    h->kt.sort += ms[1] * 1e-3;
+    h->kt.gather += ms[2] * 1e-3;
+    h->kt.density += ms[3] * 1e-3;
+    h->kt.force += ms[4] * 1e-3;
+    if (se.hasCopy) {
+        float cms;
+        HIPCHK(h, hipEventSynchronize(se.c[1]));
+        HIPCHK(h, hipEventElapsedTime(&cms, se.c[0], se.c[1]));
+        h->kt.readback += cms * 1e-3;
+    }
+    h->kt.steps += 1;
+    se.counted = true;
+    se.used = false;
+    return SPH_OK;
+}
+
+int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
+    if (n != h->n) return fail(h, SPH_EINVAL, "particle count differs from settings");
+    const float hh = h->settings.h;
+    const int D = h->P.D;
+    std::vector<float4> p4((size_t)n), v4((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+        int cx = (int)(x / hh), cy = (int)(y / hh), cz = (int)(z / hh);
+        if (!(x == x && y == y && z == z) || cx < 0 || cx >= D || cy < 0 || cy >= D ||
+            cz < 0 || cz >= D || x < 0.f || y < 0.f || z < 0.f)
+            return fail(h, SPH_EINVAL, "position outside the simulation box");
+        uint32_t id = (uint32_t)i;
+        float idbits;
+        memcpy(&idbits, &id, 4);
+        p4[i] = make_float4(x, y, z, idbits);
+        v4[i] = vel ? make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.f)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->compute));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    h->cur = 0;
+    if (n > 0) {
+        HIPCHK(h, hipMemcpy(h->pos4[0], p4.data(), (size_t)n * sizeof(float4),
+                            hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->vel4[0], v4.data(), (size_t)n * sizeof(float4),
+                            hipMemcpyHostToDevice));
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    h->ready = true;
+    h->gridValid = false;
+    h->phase = 0;
+    h->sorted = -1;
+    h->stepIndex = 0;
+    h->copyPending[0] = h->copyPending[1] = false;
+    return SPH_OK;
+}
+
+SweepArgs make_sweep_args(sph_handle *h) {
+    SweepArgs A{};
+    const int s = h->sorted;
+    A.pos4 = h->pos4[s];
+    A.vel4 = h->vel4[s];
+    A.cellRange = h->cellRange;
+    A.keys = h->ws.keys[h->sortedKeyBuf];
+    A.pos_out = h->pos4[s ^ 1];
+    A.vel_out = h->vel4[s ^ 1];
+    A.host_order_pos = nullptr;
+    A.force_out = h->force4;
+    A.pairCounter = nullptr;
+    A.i_begin = 0;
+    A.i_end = h->n;
+    A.n_all = h->n;
+    return A;
+}
+
+int begin_step_events(sph_handle *h) {
+    StepEvents &se = h->ring[h->ringHead];
+    if (se.used) {
+        int rc = resolve_events(h, se);
+        if (rc) return rc;
+    }
+    se.used = true;
+    se.counted = false;
+    se.hasCopy = false;
+    h->curEv = &se;
+    h->ringHead = (h->ringHead + 1) % kEventRing;
+    return SPH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *sph_build_info(void) {
+    return "libsph_hip gfx950 (MI355X/CDNA4), api v1, strict-fp32 sweeps, "
+           "8-bit LSD radix grid build";
+}
+
+int sph_default_settings(SphSettings *out, int numParticles, int randomInit) {
+    if (!out) return SPH_EINVAL;
+    // main.cpp:57-63
+    float h = .1f;
+    float h_pow_6 = (float)pow((double)h, 6.0);
+    float h_pow_9 = (float)pow((double)h, 9.0);
+    float v_kernel_coeff = 45.f / (3.14159265f * h_pow_6);
+    float d_kernel_coeff = 315.f / (64.f * 3.14159265f * h_pow_9);
+    memset(out, 0, sizeof(*out));
+    out->randomInit = randomInit ? 1 : 0;
+    out->numParticles = numParticles;
+    out->h = h;
+    out->v_kernel_coeff = v_kernel_coeff;
+    out->d_kernel_coeff = d_kernel_coeff;
+    out->boxDim = 10.f;
+    out->numCellsPerDim = 100;
+    out->timestep = (float).01;
+    return SPH_OK;
+}
+
+int sph_create(const SphSettings *settings, const SphOptions *options, sph_handle **out) {
+    if (!settings || !out) return fail(nullptr, SPH_EINVAL, "null argument");
+    *out = nullptr;
+    if (settings->numParticles < 0) return fail(nullptr, SPH_EINVAL, "numParticles < 0");
+    if (!(settings->h > 0.f) || !(settings->numCellsPerDim >= 1.f) ||
+        settings->numCellsPerDim > 1024.f)
+        return fail(nullptr, SPH_EINVAL, "bad h / numCellsPerDim");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, SPH_ENODEV,
+                    "no HIP device: libsph_hip has no CPU fallback by design");
+    sph_handle *h = new (std::nothrow) sph_handle();
+    if (!h) return fail(nullptr, SPH_ENOMEM, "out of host memory");
+    h->settings = *settings;
+    if (options) {
+        size_t sz = options->struct_size > 0 ? (size_t)options->struct_size : sizeof(SphOptions);
+        memcpy(&h->opt, options, sz < sizeof(SphOptions) ? sz : sizeof(SphOptions));
+    } else {
+        h->opt.device = -1;
+    }
+    h->opt.struct_size = (int32_t)sizeof(SphOptions);
+    if (h->opt.math_mode != SPH_MATH_STRICT) {
+        delete h;
+        return fail(nullptr, SPH_EINVAL, "only SPH_MATH_STRICT is implemented");
+    }
+    h->n = settings->numParticles;
+    h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
+    fill_params(h);
+    int rc = SPH_OK;
+    do {
+        if (h->opt.device >= 0) {
+            if (h->opt.device >= count) { rc = fail(nullptr, SPH_EINVAL, "device ordinal out of range"); break; }
+            if (hipSetDevice(h->opt.device) != hipSuccess) { rc = fail(nullptr, SPH_EHIP, "hipSetDevice failed"); break; }
+        }
+        if (hipGetDevice(&h->device) != hipSuccess) { rc = fail(nullptr, SPH_EHIP, "hipGetDevice failed"); break; }
+        if (hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(nullptr, SPH_EHIP, "hipStreamCreate failed");
+            break;
+        }
+        rc = alloc_device(h);
+        if (rc) g_create_error = h->err;
+    } while (0);
+    if (rc) {
+        sph_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SPH_OK;
+}
+
+void sph_destroy(sph_handle *h) {
+    if (!h) return;
+    if (h->compute) (void)hipStreamSynchronize(h->compute);
+    if (h->copy) (void)hipStreamSynchronize(h->copy);
+    for (int b = 0; b < 2; ++b) {
+        if (h->pos4[b]) (void)hipFree(h->pos4[b]);
+        if (h->vel4[b]) (void)hipFree(h->vel4[b]);
+        if (h->ws.keys[b]) (void)hipFree(h->ws.keys[b]);
+        if (h->ws.vals[b]) (void)hipFree(h->ws.vals[b]);
+        if (h->devPos[b]) (void)hipFree(h->devPos[b]);
+        if (h->computeDone[b]) (void)hipEventDestroy(h->computeDone[b]);
+        if (h->copyDone[b]) (void)hipEventDestroy(h->copyDone[b]);
+    }
+    if (h->ws.blockHist) (void)hipFree(h->ws.blockHist);
+    if (h->ws.digitTotal) (void)hipFree(h->ws.digitTotal);
+    if (h->cellRange) (void)hipFree(h->cellRange);
+    if (h->hostPos) (void)hipHostFree(h->hostPos);
+    if (h->force4) (void)hipFree(h->force4);
+    if (h->pairCounter) (void)hipFree(h->pairCounter);
+    if (h->pairHost) (void)hipHostFree(h->pairHost);
+    for (auto &se : h->ring) {
+        for (auto &e : se.e) if (e) (void)hipEventDestroy(e);
+        for (auto &e : se.c) if (e) (void)hipEventDestroy(e);
+    }
+    if (h->compute) (void)hipStreamDestroy(h->compute);
+    if (h->copy) (void)hipStreamDestroy(h->copy);
+    delete h;
+}
+
+int sph_setup(sph_handle *h) {
+    if (!h) return SPH_EINVAL;
+    const int n = h->n;
+    std::vector<float> pos((size_t)(n > 0 ? n : 1) * 3, 0.f);
+    int written = init_positions_reference(h->settings, pos.data());
+    if (written < n) {
+        fprintf(stderr,
+                "sph: -i grid holds at most %d lattice points in the reference "
+                "(simulator.cu:439-452); n=%d uses the dense-lattice EXTENSION\n",
+                written, n);
+        init_positions_dense(h->settings, pos.data());
+    }
+    return upload_common(h, pos.data(), nullptr, n);
+}
+
+int sph_upload_state(sph_handle *h, const float *pos_xyz, const float *vel_xyz, int n) {
+    if (!h || (!pos_xyz && n > 0)) return fail(h, SPH_EINVAL, "null argument");
+    return upload_common(h, pos_xyz, vel_xyz, n);
+}
+
+int sph_phase_grid(sph_handle *h) {
+    if (!h) return SPH_EINVAL;
+    if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
+    if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "grid phase out of order");
+    hipStream_t s = h->compute;
+    StepEvents *ev = h->curEv;
+    const int c = h->cur, n = h->n;
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[0], s));
+    // kernelResetGrid (simulator.cu:321-326,492-495): 8 MB memset, not 10^6 blocks
+    HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
+    sph_launch_hash(h->P, h->pos4[c], h->ws.keys[0], h->ws.vals[0], n, s);
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
+    int res = sph_sort_pairs(h->ws, n, key_bits(h), s);
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
+    sph_launch_gather(h->pos4[c], h->vel4[c], h->ws.vals[res], h->ws.keys[res],
+                      h->pos4[c ^ 1], h->vel4[c ^ 1], h->cellRange, n, s);
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[3], s));
+    HIPCHK(h, hipGetLastError());
+    h->sorted = c ^ 1;
+    h->sortedKeyBuf = res;
+    h->gridValid = true;
+    h->phase = 1;
+    return SPH_OK;
+}
+
+int sph_phase_density(sph_handle *h) {
+    if (!h) return SPH_EINVAL;
+    if (h->phase != 1) return fail(h, SPH_ESTATE, "density phase needs the grid phase first");
+    SweepArgs A = make_sweep_args(h);
+    if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
+    sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
+    if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->e[4], h->compute));
+    HIPCHK(h, hipGetLastError());
+    h->phase = 2;
+    return SPH_OK;
+}
+
+int sph_phase_force(sph_handle *h) {
+    if (!h) return SPH_EINVAL;
+    if (h->phase != 2) return fail(h, SPH_ESTATE, "force phase needs the density phase first");
+    SweepArgs A = make_sweep_args(h);
+    const int slot = (int)(h->stepIndex & 1);
+    if (!(h->opt.flags & SPH_FLAG_NO_READBACK)) {
+        // devPos[slot] was last read by the copy of step k-2
+        if (h->copyPending[slot]) {
+            HIPCHK(h, hipStreamWaitEvent(h->compute, h->copyDone[slot], 0));
+            h->copyPending[slot] = false;
+        }
+        A.host_order_pos = h->devPos[slot];
+    }
+    sph_launch_force(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
+    if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->e[5], h->compute));
+    HIPCHK(h, hipGetLastError());
+    h->cur = h->sorted ^ 1; // new state, still in this step's sorted order
+    h->phase = 3;
+    return SPH_OK;
+}
+
+int sph_phase_readback(sph_handle *h) {
+    if (!h) return SPH_EINVAL;
+    if (h->phase != 3) return fail(h, SPH_ESTATE, "readback needs the force phase first");
+    if (h->opt.flags & SPH_FLAG_NO_READBACK) {
+        h->stepIndex++;
+        h->phase = 0;
+        return SPH_OK;
+    }
+    const int slot = (int)(h->stepIndex & 1);
+    HIPCHK(h, hipEventRecord(h->computeDone[slot], h->compute));
+    HIPCHK(h, hipStreamWaitEvent(h->copy, h->computeDone[slot], 0));
+    if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->c[0], h->copy));
+    if (h->n > 0)
+        HIPCHK(h, hipMemcpyAsync(h->hostPos, h->devPos[slot], (size_t)h->n * 3 * sizeof(float),
+                                 hipMemcpyDeviceToHost, h->copy));
+    if (h->curEv) {
+        HIPCHK(h, hipEventRecord(h->curEv->c[1], h->copy));
+        h->curEv->hasCopy = true;
+    }
+    HIPCHK(h, hipEventRecord(h->copyDone[slot], h->copy));
+    h->copyPending[slot] = true;
+    h->stepIndex++;
+    h->phase = 0;
+    return SPH_OK;
+}
+
+int sph_step(sph_handle *h, SphTimes *times) {
+    if (!h) return SPH_EINVAL;
+    if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
+    int rc;
+    double waited = 0.0;
+    if (times) {
+        // "Data transfer" = the part of the previous step's D2H the pipeline
+        // could not hide (the reference blocks for the whole copy instead).
+        auto t0 = std::chrono::steady_clock::now();
+        HIPCHK(h, hipStreamSynchronize(h->copy));
+        waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if ((rc = begin_step_events(h))) return rc;
+    StepEvents *ev = h->curEv;
+    if ((rc = sph_phase_grid(h))) return rc;
+    if ((rc = sph_phase_density(h))) return rc;
+    if ((rc = sph_phase_force(h))) return rc;
+    if ((rc = sph_phase_readback(h))) return rc; // ends the step
+    h->curEv = nullptr;
+    if (times) {
+        HIPCHK(h, hipStreamSynchronize(h->compute));
+        float gridMs = 0.f, sphMs = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&gridMs, ev->e[0], ev->e[3]));
+        HIPCHK(h, hipEventElapsedTime(&sphMs, ev->e[3], ev->e[5]));
+        times->buildGrid += gridMs * 1e-3;
+        times->sphUpdate += sphMs * 1e-3;
+        times->memcpy += waited;
+        times->iters += 1;
+    }
+    return SPH_OK;
+}
+
+int sph_apply_click(sph_handle *h, int mx, int my) {
+    if (!h) return SPH_EINVAL;
+    if (!h->gridValid || h->phase != 0 || h->stepIndex == 0)
+        return fail(h, SPH_ESTATE, "click needs a completed step (it reuses that step's grid)");
+    sph_launch_click(h->P, h->cellRange, h->vel4[h->cur], mx, my, h->compute);
+    HIPCHK(h, hipGetLastError());
+    return SPH_OK;
+}
+
+const float *sph_positions_host(sph_handle *h) {
+    if (!h) return nullptr;
+    if (hipStreamSynchronize(h->compute) != hipSuccess ||
+        hipStreamSynchronize(h->copy) != hipSuccess) {
+        h->err = "stream synchronize failed";
+        return nullptr;
+    }
+    return h->hostPos;
+}
+
+int sph_sync(sph_handle *h) {
+    if (!h) return SPH_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->compute));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    return SPH_OK;
+}
+
+int sph_num_particles(const sph_handle *h) { return h ? h->n : SPH_EINVAL; }
+
+int sph_download_state(sph_handle *h, float *pos, float *vel, float *rho, float *prs) {
+    if (!h) return SPH_EINVAL;
+    if (!h->ready) return fail(h, SPH_ESTATE, "no state");
+    int rc = sph_sync(h);
+    if (rc) return rc;
+    const int n = h->n;
+    std::vector<float4> p4((size_t)(n > 0 ? n : 1)), v4((size_t)(n > 0 ? n : 1));
+    if (n > 0) {
+        HIPCHK(h, hipMemcpy(p4.data(), h->pos4[h->cur], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(v4.data(), h->vel4[h->cur], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < n; ++i) {
+        uint32_t id;
+        memcpy(&id, &p4[i].w, 4);
+        if (id >= (uint32_t)n) return fail(h, SPH_EHIP, "corrupt particle id in device state");
+        if (pos) { pos[3 * id] = p4[i].x; pos[3 * id + 1] = p4[i].y; pos[3 * id + 2] = p4[i].z; }
+        if (vel) { vel[3 * id] = v4[i].x; vel[3 * id + 1] = v4[i].y; vel[3 * id + 2] = v4[i].z; }
+        float r = v4[i].w;
+        if (rho) rho[id] = r;
+        // same expression as simulator.cu:188-189
+        if (prs) prs[id] = fmaxf(0.f, SPH_GAS_CONSTANT * (r - SPH_REST_DENSITY));
+    }
+    return SPH_OK;
+}
+
+int sph_download_force(sph_handle *h, float *force_xyz) {
+    if (!h || !force_xyz) return SPH_EINVAL;
+    if (!h->force4) return fail(h, SPH_ESTATE, "create with SPH_FLAG_STORE_FORCE");
+    int rc = sph_sync(h);
+    if (rc) return rc;
+    const int n = h->n;
+    std::vector<float4> f4((size_t)(n > 0 ? n : 1)), p4((size_t)(n > 0 ? n : 1));
+    if (n > 0) {
+        HIPCHK(h, hipMemcpy(f4.data(), h->force4, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(p4.data(), h->pos4[h->cur], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < n; ++i) {
+        uint32_t id;
+        memcpy(&id, &p4[i].w, 4);
+        if (id >= (uint32_t)n) return fail(h, SPH_EHIP, "corrupt particle id in device state");
+        force_xyz[3 * id] = f4[i].x;
+        force_xyz[3 * id + 1] = f4[i].y;
+        force_xyz[3 * id + 2] = f4[i].z;
+    }
+    return SPH_OK;
+}
+
+int sph_download_grid(sph_handle *h, uint32_t *ids, uint32_t *keys, int32_t *cell_ranges) {
+    if (!h) return SPH_EINVAL;
+    if (!h->gridValid) return fail(h, SPH_ESTATE, "no grid built yet");
+    int rc = sph_sync(h);
+    if (rc) return rc;
+    const int n = h->n;
+    if (ids && n > 0) {
+        std::vector<float4> p4((size_t)n);
+        HIPCHK(h, hipMemcpy(p4.data(), h->pos4[h->sorted], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) memcpy(&ids[i], &p4[i].w, 4);
+    }
+    if (keys && n > 0)
+        HIPCHK(h, hipMemcpy(keys, h->ws.keys[h->sortedKeyBuf], (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cell_ranges)
+        HIPCHK(h, hipMemcpy(cell_ranges, h->cellRange, (size_t)h->P.numCells * sizeof(int2), hipMemcpyDeviceToHost));
+    return SPH_OK;
+}
+
+int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
+    if (!h || !out) return SPH_EINVAL;
+    int rc = sph_sync(h);
+    if (rc) return rc;
+    for (auto &se : h->ring)
+        if ((rc = resolve_events(h, se))) return rc;
+    if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) {
+        HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        h->kt.pair_tests = *h->pairHost;
+    }
+    *out = h->kt;
+    if (reset) {
+        h->kt = SphKernelTimes{};
+        HIPCHK(h, hipMemset(h->pairCounter, 0, sizeof(unsigned long long)));
+    }
+    return SPH_OK;
+}
+
+const char *sph_last_error(const sph_handle *h) {
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int sph_sort_check(int device, const uint32_t *keys, int n, int key_bits_, uint32_t *perm_out,
+                   uint32_t *sorted_keys_out) {
+    if (n < 0 || (n > 0 && !keys)) return SPH_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SPH_ENODEV;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return SPH_EHIP;
+    if (n == 0) return SPH_OK;
+    SortWorkspace ws{};
+    int rc = SPH_OK;
+    std::vector<uint32_t> iota((size_t)n);
+    for (int i = 0; i < n; ++i) iota[i] = (uint32_t)i;
+    size_t nb = sph_sort_workspace_blocks(n);
+    bool ok = true;
+    for (int b = 0; b < 2 && ok; ++b) {
+        ok = ok && hipMalloc(&ws.keys[b], (size_t)n * 4) == hipSuccess;
+        ok = ok && hipMalloc(&ws.vals[b], (size_t)n * 4) == hipSuccess;
+    }
+    ok = ok && hipMalloc(&ws.blockHist, 256 * nb * 4) == hipSuccess;
+    ok = ok && hipMalloc(&ws.digitTotal, 256 * 4) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b) {
+        ok = ok && hipMemset(ws.keys[b], 0, (size_t)n * 4) == hipSuccess;
+        ok = ok && hipMemset(ws.vals[b], 0, (size_t)n * 4) == hipSuccess;
+    }
+    if (ok) {
+        ws.capacity = n;
+        ws.maxBlocks = (int)nb;
+        ok = ok && hipMemcpy(ws.keys[0], keys, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(ws.vals[0], iota.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess;
+        int res = sph_sort_pairs(ws, n, key_bits_, nullptr);
+        ok = ok && hipDeviceSynchronize() == hipSuccess;
+        if (ok && perm_out)
+            ok = hipMemcpy(perm_out, ws.vals[res], (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && sorted_keys_out)
+            ok = hipMemcpy(sorted_keys_out, ws.keys[res], (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) rc = SPH_EHIP;
+    for (int b = 0; b < 2; ++b) {
+        if (ws.keys[b]) (void)hipFree(ws.keys[b]);
+        if (ws.vals[b]) (void)hipFree(ws.vals[b]);
+    }
+    if (ws.blockHist) (void)hipFree(ws.blockHist);
+    if (ws.digitTotal) (void)hipFree(ws.digitTotal);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units of libsph_hip.so.
+// gfx950 (MI355X / CDNA4) only: wavefront = 64 lanes is hard-coded throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPH_WAVE 64
+
+// Physics constants of the reference (simulator.h:6-12, simulator.cu:13-14).
+#define SPH_MASS 0.02f
+#define SPH_GAS_CONSTANT 1.f
+#define SPH_REST_DENSITY 1000.f
+#define SPH_VISCOSITY 1.f
+#define SPH_GRAVITY -9.8f
+#define SPH_ELASTICITY 0.5f
+#define SPH_EPS_F (1e-4f)
+#define SPH_PUSH_STRENGTH (5.f)
+#define SPH_BOX_MAX_X (600)
+#define SPH_BOX_MIN_X (200)
+#define SPH_BOX_MAX_Y (450)
+#define SPH_BOX_MIN_Y (150)
+
+// Run constants, passed to every kernel by value (they land in SGPRs; this
+// replaces the reference's `__constant__ Settings deviceSettings`,
+// simulator.cu:19,459).
+struct DevParams {
+    float h;       // smoothing radius = cell size
+    float h2;      // h*h, rounded once in fp32 (simulator.cu:89,105)
+    float vcoef;   // v_kernel_coeff
+    float dcoef;   // d_kernel_coeff
+    float boxDim;
+    float boxHi;   // boxDim - h in fp32 (simulator.cu:283)
+    float dt;      // timestep
+    float cut2;    // largest dist2 for which ANY force term can be non-zero
+    int D;         // cells per dimension (numCellsPerDim as int)
+    int numCells;  // D^3
+};
+
+// Particle state lives in two float4 streams, both in cell-sorted order:
+//   pos4[i] = (x, y, z, bits(original particle id))
+//   vel4[i] = (vx, vy, vz, rho_i)      rho filled by the density sweep
+// 32 B per particle instead of the reference's 56-B AoS with a list pointer
+// (simulator.h:33-51); a neighbour test touches 16 B.
+
+// ---- radix sort (sort.hip) ----
+struct SortWorkspace {
+    uint32_t *keys[2];
+    uint32_t *vals[2];
+    uint32_t *blockHist;  // [256][numBlocks], digit-major
+    uint32_t *digitTotal; // [256]
+    int capacity;         // elements
+    int maxBlocks;
+};
+size_t sph_sort_workspace_blocks(int n);
+// Stable LSD sort of (keys[0], vals[0]) on `bits` key bits; returns the index
+// (0/1) of the buffer pair that holds the result.
+int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s);
+
+// ---- grid build (grid.hip) ----
+void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
+                     uint32_t *vals, int n, hipStream_t s);
+void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
+                       const uint32_t *perm, const uint32_t *sorted_keys,
+                       float4 *pos_out, float4 *vel_out, int2 *cellRange, int n,
+                       hipStream_t s);
+void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4,
+                      int mx, int my, hipStream_t s);
+
+// ---- sweeps (sweeps.hip) ----
+struct SweepArgs {
+    const float4 *pos4;       // sorted positions (+id)
+    float4 *vel4;             // sorted velocities (+rho): density writes .w
+    const int2 *cellRange;    // {start,end} per flattened cell
+    const uint32_t *keys;     // sorted flattened cell keys
+    float4 *pos_out;          // force+integrate outputs (same sorted index)
+    float4 *vel_out;
+    float *host_order_pos;    // n x 3 floats by original id (may be null)
+    float4 *force_out;        // optional (SPH_FLAG_STORE_FORCE)
+    unsigned long long *pairCounter; // optional (SPH_FLAG_COUNT_PAIRS)
+    int i_begin, i_end;       // owned range (whole array for one domain)
+    int n_all;
+};
+void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode,
+                        int sweep, hipStream_t s);
+void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode,
+                      int sweep, hipStream_t s);

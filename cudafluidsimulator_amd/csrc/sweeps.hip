@@ -1,0 +1,391 @@
+// Density/pressure sweep and fused force + integration sweep over the key-sorted
+// float4 particle streams -- the gfx950 replacements for
+// kernelUpdatePressureAndDensity (simulator.cu:149-190), kernelUpdateForces
+// (simulator.cu:192-256) and kernelUpdatePositions (simulator.cu:258-318).
+//
+// THIS FILE MUST BE COMPILED WITH -ffp-contract=off: in strict mode every fp32
+// operation rounds on its own, in the order the reference's expressions are
+// written, so results are bit-identical to oracle/sph_oracle.c.
+//
+// Neighbour walk.  With the flattened key (x fastest) the reference's 27-cell
+// walk (dz outer, dy, dx inner; simulator.cu:163-176) is nine contiguous index
+// ranges of the sorted stream ("runs": cells x-1..x+1 of row (y+dy, z+dz)),
+// visited in ascending order -- which is the canonical summation order.
+//
+// Production variant (SPH_SWEEP_LDS): every 64-lane wave is autonomous (no
+// workgroup barrier).  It owns 64 consecutive sorted particles, groups its
+// lanes by grid row, and for each of the nine runs stages the UNION of its
+// lanes' ranges into its private LDS slice in chunks of SW_CAP float4
+// (coalesced 16-B loads -> ds_write_b128), then each lane walks ITS OWN
+// sub-range with ds_read_b128.  Chunking makes the window independent of the
+// per-cell particle count (the reference's lists are unbounded too).
+//
+// Force sweep: only ~15 % of the candidates of a 27-cell box lie inside the
+// support radius, and the in-radius body is ~10x the cost of the distance test
+// (2 sqrt + 3 IEEE divides).  Running the body under a divergent mask would
+// cost the full body on every candidate, so the test loop only PUSHES hits
+// into a per-lane FIFO in LDS; whenever some lane's FIFO is full the whole
+// wave pops one entry each and runs the body once.  Hits are consumed in push
+// order, so every particle still accumulates its neighbours in canonical
+// order, and skipped candidates contribute exactly +-0 in the reference, which
+// never changes an accumulator that is not -0 (it never is: sums start at +0).
+#include "sph_device.h"
+
+#define SW_THREADS 256
+#define SW_WAVES (SW_THREADS / SPH_WAVE)
+#define SW_CAP 256  // staged candidates per chunk per wave (4 KiB)
+#define SW_QCAP 16  // hit-FIFO entries per lane (4 KiB per wave)
+
+__device__ __forceinline__ int3 sweep_cell(const DevParams &P, float x, float y,
+                                           float z) {
+    int3 c;
+    c.x = min(max((int)(x / P.h), 0), P.D - 1);
+    c.y = min(max((int)(y / P.h), 0), P.D - 1);
+    c.z = min(max((int)(z / P.h), 0), P.D - 1);
+    return c;
+}
+
+// The nine runs of one particle: [js[r], je[r]) in sorted-stream indices,
+// r = (dz+1)*3 + (dy+1).  Empty runs are {0,0}.
+__device__ __forceinline__ void load_runs(const DevParams &P,
+                                          const int2 *__restrict__ cellRange,
+                                          int3 c, bool valid, int (&js)[9],
+                                          int (&je)[9]) {
+    const int x0 = max(c.x - 1, 0), x1 = min(c.x + 1, P.D - 1);
+    const int xm = min(x0 + 1, x1);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int sz = c.z + (r / 3 - 1), sy = c.y + (r % 3 - 1);
+        js[r] = 0;
+        je[r] = 0;
+        if (valid && sy >= 0 && sy < P.D && sz >= 0 && sz < P.D) {
+            const int base = sy * P.D + sz * P.D * P.D;
+            int2 r0 = cellRange[base + x0];
+            int2 r1 = cellRange[base + xm];
+            int2 r2 = cellRange[base + x1];
+            bool n0 = r0.y > r0.x, n1 = r1.y > r1.x, n2 = r2.y > r2.x;
+            if (n0 | n1 | n2) {
+                js[r] = n0 ? r0.x : (n1 ? r1.x : r2.x);
+                je[r] = n2 ? r2.y : (n1 ? r1.y : r0.y);
+            }
+        }
+    }
+}
+
+// ---- per-pair arithmetic (strict: individually rounded, reference order) ----
+
+// densityKernel (simulator.cu:84-97) folded with `density += MASS * W` (:179).
+__device__ __forceinline__ void density_pair(const DevParams &P, float pix, float piy,
+                                             float piz, float4 pj, float &rho) {
+    float dx = pix - pj.x;
+    float dy = piy - pj.y;
+    float dz = piz - pj.z;
+    float dist2 = dx * dx + dy * dy + dz * dz;
+    if (!(dist2 > P.h2)) {
+        float diff = P.h2 - dist2;
+        rho += SPH_MASS * (P.dcoef * diff * diff * diff);
+    }
+}
+
+struct ForceAcc {
+    float fx, fy, fz;
+};
+
+// One neighbour of kernelUpdateForces (simulator.cu:223-251) with
+// pressureKernel (:99-117) and viscosityKernel (:119-130) inlined.
+__device__ __forceinline__ void force_pair(const DevParams &P, float pix, float piy,
+                                           float piz, float vix, float viy, float viz,
+                                           float prs_i, float4 pj, float4 vj,
+                                           ForceAcc &F) {
+    float dx = pix - pj.x;
+    float dy = piy - pj.y;
+    float dz = piz - pj.z;
+    float dist2 = dx * dx + dy * dy + dz * dz;
+    float rho_j = vj.w;
+    float prs_j = fmaxf(0.f, SPH_GAS_CONSTANT * (rho_j - SPH_REST_DENSITY));
+    float dist = sqrtf(dist2);
+    bool tiny = dist < SPH_EPS_F;
+    if (!(dist2 > P.h2) && !tiny) {
+        float fPressure = -SPH_MASS * (prs_i + prs_j) / (2.f * rho_j);
+        float scale = (-P.vcoef) * (P.h - dist) * (P.h - dist) / dist;
+        float kx = dx * scale, ky = dy * scale, kz = dz * scale;
+        kx *= fPressure;
+        ky *= fPressure;
+        kz *= fPressure;
+        F.fx += kx;
+        F.fy += ky;
+        F.fz += kz;
+    }
+    if (!(dist > P.h) && !tiny) {
+        float fViscosity =
+            SPH_VISCOSITY * SPH_MASS * (P.vcoef * (P.h - dist)) / rho_j;
+        float dvx = vj.x - vix, dvy = vj.y - viy, dvz = vj.z - viz;
+        dvx *= fViscosity;
+        dvy *= fViscosity;
+        dvz *= fViscosity;
+        F.fx += dvx;
+        F.fy += dvy;
+        F.fz += dvz;
+    }
+}
+
+// kernelUpdatePositions (simulator.cu:258-318).
+__device__ __forceinline__ void integrate_particle(const DevParams &P, float4 &p,
+                                                   float &vx, float &vy, float &vz,
+                                                   const ForceAcc &F, float density) {
+    const float timestep = P.dt;
+    vx += timestep * F.fx / density;
+    vy += timestep * (F.fy / density + SPH_GRAVITY);
+    vz += timestep * F.fz / density;
+
+    p.x += timestep * vx;
+    p.y += timestep * vy;
+    p.z += timestep * vz;
+
+    if (p.x < P.h) { p.x = P.h; vx *= -SPH_ELASTICITY; }
+    else if (p.x > P.boxHi) { p.x = P.boxHi; vx *= -SPH_ELASTICITY; }
+    if (p.y < P.h) { p.y = P.h; vy *= -SPH_ELASTICITY; }
+    else if (p.y > P.boxHi) { p.y = P.boxHi; vy *= -SPH_ELASTICITY; }
+    if (p.z < P.h) { p.z = P.h; vz *= -SPH_ELASTICITY; }
+    else if (p.z > P.boxHi) { p.z = P.boxHi; vz *= -SPH_ELASTICITY; }
+
+    if (fabsf(vx) < SPH_EPS_F) vx = 0;
+    if (fabsf(vy) < SPH_EPS_F) vy = 0;
+    if (fabsf(vz) < SPH_EPS_F) vz = 0;
+}
+
+__device__ __forceinline__ void store_particle(const SweepArgs &A, int i, float4 p,
+                                               float vx, float vy, float vz,
+                                               float rho, const ForceAcc &F) {
+    A.pos_out[i] = p;
+    A.vel_out[i] = make_float4(vx, vy, vz, rho);
+    if (A.host_order_pos) {
+        // devicePosition[pIdx] = position (simulator.cu:317): original-id order
+        uint32_t id = __float_as_uint(p.w);
+        float *o = A.host_order_pos + 3 * (size_t)id;
+        o[0] = p.x;
+        o[1] = p.y;
+        o[2] = p.z;
+    }
+    if (A.force_out) A.force_out[i] = make_float4(F.fx, F.fy, F.fz, 0.f);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// =====================  DIRECT variant (check path)  =========================
+__global__ __launch_bounds__(SW_THREADS) void k_density_direct(DevParams P,
+                                                               SweepArgs A) {
+    int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = i < A.i_end;
+    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, valid, js, je);
+    float rho = 0.f;
+    uint32_t pairs = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        pairs += (uint32_t)(je[r] - js[r]);
+        for (int j = js[r]; j < je[r]; ++j) density_pair(P, pi.x, pi.y, pi.z, A.pos4[j], rho);
+    }
+    if (A.pairCounter) {
+        uint32_t s = wave_sum_u32(pairs);
+        if ((threadIdx.x & 63) == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
+    }
+    if (valid) {
+        rho = fmaxf(rho, SPH_EPS_F);
+        A.vel4[i].w = rho;
+    }
+}
+
+__global__ __launch_bounds__(SW_THREADS) void k_force_direct(DevParams P, SweepArgs A) {
+    int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.i_end) return;
+    float4 pi = A.pos4[i];
+    float4 vi = A.vel4[i];
+    float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, true, js, je);
+    ForceAcc F = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        for (int j = js[r]; j < je[r]; ++j)
+            force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j],
+                       F);
+    }
+    float vx = vi.x, vy = vi.y, vz = vi.z;
+    integrate_particle(P, pi, vx, vy, vz, F, vi.w);
+    store_particle(A, i, pi, vx, vy, vz, vi.w, F);
+}
+
+// =====================  LDS variant (production)  ============================
+// Walks the nine runs of the lanes of one wave.  `V.candidate(j, pj, active)` is
+// called once per loop trip for every lane (active = this lane really has a
+// candidate); `V.poll()` is called wave-uniformly after each trip.
+template <class Visitor>
+__device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict__ stage,
+                                          int lane, bool valid, int rowId,
+                                          const int (&js)[9], const int (&je)[9],
+                                          Visitor &V) {
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int rowL = __builtin_amdgcn_readlane(rowId, leader);
+        const bool act = valid && rowId == rowL;
+        todo &= ~__ballot(act);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const bool nonempty = act && je[r] > js[r];
+            const unsigned long long m = __ballot(nonempty);
+            if (!m) continue;
+            // lanes are key-sorted, so run bounds are monotone over the lanes
+            const int lo = __ffsll((long long)m) - 1;
+            const int hi = 63 - __clzll((long long)m);
+            const int u0 = __builtin_amdgcn_readlane(js[r], lo);
+            const int u1 = __builtin_amdgcn_readlane(je[r], hi);
+            for (int cs = u0; cs < u1; cs += SW_CAP) {
+                const int len = min(SW_CAP, u1 - cs);
+                for (int k = lane; k < len; k += SPH_WAVE) stage[k] = A.pos4[cs + k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int a = nonempty ? max(js[r], cs) : 0;
+                const int b = nonempty ? min(je[r], cs + len) : 0;
+                while (__ballot(a < b)) {
+                    const bool on = a < b;
+                    float4 pj = stage[on ? (a - cs) : 0];
+                    V.candidate(a, pj, on);
+                    V.poll();
+                    ++a;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+struct DensityVisitor {
+    const DevParams &P;
+    float pix, piy, piz;
+    float rho;
+    __device__ __forceinline__ void candidate(int, float4 pj, bool on) {
+        if (on) density_pair(P, pix, piy, piz, pj, rho);
+    }
+    __device__ __forceinline__ void poll() {}
+};
+
+__global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepArgs A) {
+    __shared__ float4 stageAll[SW_WAVES][SW_CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 *stage = stageAll[w];
+    const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < A.i_end;
+    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, valid, js, je);
+    if (A.pairCounter) {
+        uint32_t pairs = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) pairs += (uint32_t)(je[r] - js[r]);
+        uint32_t s = wave_sum_u32(pairs);
+        if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
+    }
+    DensityVisitor V{P, pi.x, pi.y, pi.z, 0.f};
+    wave_walk(A, stage, lane, valid, c.y + c.z * P.D, js, je, V);
+    if (valid) {
+        float rho = fmaxf(V.rho, SPH_EPS_F);
+        A.vel4[i].w = rho;
+    }
+}
+
+struct ForceVisitor {
+    const DevParams &P;
+    const SweepArgs &A;
+    uint32_t *queue; // this wave's FIFO storage: [SW_QCAP][64]
+    int lane;
+    float pix, piy, piz, vix, viy, viz, prs_i;
+    uint32_t head, tail;
+    ForceAcc F;
+
+    __device__ __forceinline__ void candidate(int j, float4 pj, bool on) {
+        float dx = pix - pj.x;
+        float dy = piy - pj.y;
+        float dz = piz - pj.z;
+        float dist2 = dx * dx + dy * dy + dz * dz;
+        if (on && !(dist2 > P.cut2)) {
+            queue[(tail & (SW_QCAP - 1)) * SPH_WAVE + lane] = (uint32_t)j;
+            ++tail;
+        }
+    }
+    // pop one hit per lane and evaluate it
+    __device__ __forceinline__ void drain_one() {
+        const bool has = tail != head;
+        uint32_t j = queue[(head & (SW_QCAP - 1)) * SPH_WAVE + lane];
+        if (has) {
+            ++head;
+            float4 pj = A.pos4[j];
+            float4 vj = A.vel4[j];
+            force_pair(P, pix, piy, piz, vix, viy, viz, prs_i, pj, vj, F);
+        }
+    }
+    __device__ __forceinline__ void poll() {
+        // a full FIFO anywhere in the wave forces one body iteration
+        while (__ballot((tail - head) >= SW_QCAP)) drain_one();
+    }
+    __device__ __forceinline__ void flush() {
+        while (__ballot(tail != head)) drain_one();
+    }
+};
+
+__global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs A) {
+    __shared__ float4 stageAll[SW_WAVES][SW_CAP];
+    __shared__ uint32_t queueAll[SW_WAVES][SW_QCAP * SPH_WAVE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < A.i_end;
+    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
+    float4 vi = valid ? A.vel4[i] : make_float4(0, 0, 0, 1.f);
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, valid, js, je);
+    ForceVisitor V{P, A, queueAll[w], lane, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
+                   fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY)),
+                   0u, 0u, {0.f, 0.f, 0.f}};
+    wave_walk(A, stageAll[w], lane, valid, c.y + c.z * P.D, js, je, V);
+    V.flush();
+    if (valid) {
+        float vx = vi.x, vy = vi.y, vz = vi.z;
+        integrate_particle(P, pi, vx, vy, vz, V.F, vi.w);
+        store_particle(A, i, pi, vx, vy, vz, vi.w, V.F);
+    }
+}
+
+void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode, int sweep,
+                        hipStream_t s) {
+    (void)mathMode;
+    int cnt = A.i_end - A.i_begin;
+    if (cnt <= 0) return;
+    int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
+    if (sweep == 1)
+        k_density_direct<<<blocks, SW_THREADS, 0, s>>>(P, A);
+    else
+        k_density_lds<<<blocks, SW_THREADS, 0, s>>>(P, A);
+}
+
+void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode, int sweep,
+                      hipStream_t s) {
+    (void)mathMode;
+    int cnt = A.i_end - A.i_begin;
+    if (cnt <= 0) return;
+    int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
+    if (sweep == 1)
+        k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A);
+    else
+        k_force_lds<<<blocks, SW_THREADS, 0, s>>>(P, A);
+}

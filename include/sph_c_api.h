@@ -1,0 +1,152 @@
+/*
+ * sph_c_api.h -- C-ABI drop-in boundary of the MI355X SPH step path.
+ *
+ * Plain C types only (no HIP, no torch).  This is what a host program in any
+ * language binds (cgo / JNI / ctypes / the C++ `Simulator` class in
+ * include/simulator.h).  The reference has no FFI of its own -- its boundary is
+ * the C++ class in src/simulator.h:53-74 -- so each entry point cites the
+ * reference method or code it replaces.  All functions return 0 on success and
+ * a negative SPH_E* code on failure; sph_last_error() gives the message.
+ *
+ * Threading: a handle is used from one host thread at a time (the reference is
+ * single-threaded, simulator.cu:462-546).  Work is queued on the handle's own
+ * HIP streams; sph_positions_host()/sph_download_state()/sph_sync() block until
+ * the data they expose is complete, so callers observe the reference's
+ * "synchronous on return" behaviour.
+ */
+#ifndef SPH_C_API_H
+#define SPH_C_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_API_VERSION 1
+
+#define SPH_OK 0
+#define SPH_EINVAL (-1)  /* bad argument / state outside the box       */
+#define SPH_EHIP (-2)    /* a HIP runtime call failed                   */
+#define SPH_ENOMEM (-3)  /* host or device allocation failed            */
+#define SPH_ESTATE (-4)  /* call order violated (e.g. step before setup) */
+#define SPH_ENODEV (-5)  /* no usable GPU                               */
+
+/* Layout-identical to the reference's `struct Settings` (simulator.h:19-31):
+ * bool, int, 6 floats = 32 bytes.  numCellsPerDim is a float there too. */
+typedef struct SphSettings {
+    uint8_t randomInit;
+    uint8_t pad_[3];
+    int32_t numParticles;
+    float h;
+    float v_kernel_coeff;
+    float d_kernel_coeff;
+    float boxDim;
+    float numCellsPerDim;
+    float timestep;
+} SphSettings;
+
+/* Layout-identical to the reference's `struct Times` (times.h:5-10). */
+typedef struct SphTimes {
+    double buildGrid;
+    double sphUpdate;
+    double memcpy;
+    int32_t iters;
+} SphTimes;
+
+enum {
+    SPH_MATH_STRICT = 0, /* every op individually rounded; bit-identical to oracle */
+    SPH_MATH_FAST = 1    /* FMA contraction + approximate rcp/sqrt (tolerance-checked) */
+};
+enum {
+    SPH_SWEEP_LDS = 0,   /* LDS-staged neighbour window (production) */
+    SPH_SWEEP_DIRECT = 1 /* one thread per particle, direct global loads (check) */
+};
+enum {
+    SPH_FLAG_COUNT_PAIRS = 1, /* accumulate the candidate pair-test count per step */
+    SPH_FLAG_STORE_FORCE = 2, /* keep per-particle force of the last step (tests)  */
+    SPH_FLAG_NO_READBACK = 4  /* skip the per-step D2H of positions (kernel studies) */
+};
+
+typedef struct SphOptions {
+    int32_t struct_size; /* = sizeof(SphOptions) */
+    int32_t device;      /* HIP device ordinal; -1 = current */
+    int32_t math_mode;   /* SPH_MATH_* */
+    int32_t sweep;       /* SPH_SWEEP_* */
+    int32_t flags;       /* SPH_FLAG_* */
+    int32_t capacity;    /* particle slots to allocate (0 = numParticles); slabs
+                            need room for halo + migrants */
+} SphOptions;
+
+/* Per-kernel GPU time, accumulated from HIP events recorded on the handle's
+ * compute stream (seconds).  `steps` = number of steps accumulated. */
+typedef struct SphKernelTimes {
+    double hash, sort, gather, density, force, readback;
+    uint64_t pair_tests; /* sum over steps, if SPH_FLAG_COUNT_PAIRS */
+    int64_t steps;
+} SphKernelTimes;
+
+typedef struct sph_handle sph_handle;
+
+/* main.cpp:57-63 -- the constants main() derives before constructing Settings. */
+int sph_default_settings(SphSettings *out, int numParticles, int randomInit);
+
+/* Simulator::Simulator (simulator.cu:370-375).  Copies *settings. */
+int sph_create(const SphSettings *settings, const SphOptions *options,
+               sph_handle **out);
+/* Simulator::~Simulator (simulator.cu:377-405). */
+void sph_destroy(sph_handle *h);
+
+/* Simulator::setup (simulator.cu:411-460): allocate, reference initial
+ * conditions (random: glibc rand() as if never seeded; grid: 0.09 lattice),
+ * upload.  n > 109^3 in grid mode is outside the reference's domain and uses
+ * the labelled "dense lattice" extension. */
+int sph_setup(sph_handle *h);
+/* Replaces setup()'s initialiser with caller state in particle-id order
+ * (xyz interleaved; vel may be NULL = zero).  Positions must lie in the box. */
+int sph_upload_state(sph_handle *h, const float *pos_xyz, const float *vel_xyz,
+                     int n);
+
+/* Simulator::simulate (times == NULL, simulator.cu:462-497) and
+ * Simulator::simulateAndTime (times != NULL, simulator.cu:499-546). */
+int sph_step(sph_handle *h, SphTimes *times);
+/* kernelMoveParticles (simulator.cu:329-367) on the last step's grid; this is
+ * what simulate() runs when `mouseClicked` is set (simulator.cu:482-489). */
+int sph_apply_click(sph_handle *h, int mouse_x, int mouse_y);
+
+/* Simulator::getPosition (simulator.cu:407-409): numParticles x (x,y,z),
+ * original particle-id order, owned by the handle, valid until the next step.
+ * Blocks until the last step's device->host copy has landed. */
+const float *sph_positions_host(sph_handle *h);
+/* Full state in particle-id order; any pointer may be NULL. rho/prs are the
+ * values kernelUpdatePressureAndDensity produced in the last step. */
+int sph_download_state(sph_handle *h, float *pos_xyz, float *vel_xyz,
+                       float *rho, float *prs);
+int sph_download_force(sph_handle *h, float *force_xyz); /* SPH_FLAG_STORE_FORCE */
+/* Sorted-order view of the last grid build: ids, flattened cell keys
+ * (pre-integration), and the {start,end} cell table (numCells x 2 ints). */
+int sph_download_grid(sph_handle *h, uint32_t *ids, uint32_t *keys,
+                      int32_t *cell_ranges);
+
+int sph_sync(sph_handle *h);
+int sph_num_particles(const sph_handle *h);
+int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset);
+const char *sph_last_error(const sph_handle *h); /* h may be NULL: create errors */
+
+/* ---- the step split into its phases (tests, profiling, slab driver) ---- */
+int sph_phase_grid(sph_handle *h);     /* kernelBuildGrid + kernelResetGrid */
+int sph_phase_density(sph_handle *h);  /* kernelUpdatePressureAndDensity    */
+int sph_phase_force(sph_handle *h);    /* kernelUpdateForces + UpdatePositions */
+int sph_phase_readback(sph_handle *h); /* the per-step D2H (simulator.cu:479) */
+
+/* Stand-alone check of the radix sort used by the grid build: stable sort of
+ * n (key, index) pairs; writes the permutation (host pointers). */
+int sph_sort_check(int device, const uint32_t *keys, int n, int key_bits,
+                   uint32_t *perm_out, uint32_t *sorted_keys_out);
+
+const char *sph_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

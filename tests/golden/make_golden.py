@@ -1,0 +1,61 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/sph_oracle.c).
+
+The reference holds no golden vectors for this path and its CUDA
+source cannot run here, so these fixtures are ORACLE outputs: they pin the HIP
+path and the oracle to each other across rounds, not to the reference.  Data
+only: inputs are regenerated from seeds / the reference initialisers.
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from helpers import dense_block  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def _run(sim, checkpoints):
+    out = {}
+    done = 0
+    for k in checkpoints:
+        sim.step(k - done)
+        done = k
+        d = sim.download()
+        out[f"pos_{k}"] = d["pos"]
+        if k == checkpoints[0]:
+            out[f"rho_{k}"] = d["rho"]
+            out[f"vel_{k}"] = d["vel"]
+    return out
+
+
+def grid2048():
+    sim = O.OracleSim(2048, False)
+    sim.setup()
+    return _run(sim, [1, 10, 100])
+
+
+def random4096():
+    sim = O.OracleSim(4096, True)
+    sim.setup()
+    return _run(sim, [1, 10, 100])
+
+
+def dense4096():
+    pos = dense_block(16)  # rho ~ 1.3e3 > REST_DENSITY: pressure term active
+    sim = O.OracleSim(len(pos), False)
+    sim.upload(pos)
+    return _run(sim, [1, 5, 20])
+
+
+CASES = {"grid2048": grid2048, "random4096": random4096, "dense4096": dense4096}
+
+if __name__ == "__main__":
+    for name, fn in CASES.items():
+        out = fn()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, {k: v.shape for k, v in out.items()})
