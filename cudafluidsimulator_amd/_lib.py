@@ -8,6 +8,7 @@ _LIB_NAME = "libsph_hip.so"
 SPH_MATH_STRICT, SPH_MATH_FAST = 0, 1
 SPH_SWEEP_LDS, SPH_SWEEP_DIRECT = 0, 1
 SPH_FLAG_COUNT_PAIRS, SPH_FLAG_STORE_FORCE, SPH_FLAG_NO_READBACK = 1, 2, 4
+SPH_FLAG_EXTERNAL_STATE = 8
 
 # every symbol include/sph_c_api.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
@@ -16,6 +17,8 @@ EXPORTED_SYMBOLS = [
     "sph_download_force", "sph_download_grid", "sph_sync", "sph_num_particles",
     "sph_get_kernel_times", "sph_last_error", "sph_phase_grid", "sph_phase_density",
     "sph_phase_force", "sph_phase_readback", "sph_sort_check", "sph_build_info",
+    "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_density",
+    "sph_slab_force",
 ]
 
 
@@ -93,5 +96,10 @@ def load_library():
         getattr(L, name).argtypes = [hp]
     L.sph_sort_check.argtypes = [C.c_int, u32p, C.c_int, C.c_int, u32p, u32p]
     L.sph_build_info.restype = C.c_char_p
+    L.sph_set_stream.argtypes = [hp, C.c_void_p]
+    L.sph_bind_buffers.argtypes = [hp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.sph_slab_sort.argtypes = [hp, C.c_int, C.c_int, C.c_int, u32p, C.c_int, i32p]
+    L.sph_slab_density.argtypes = [hp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.sph_slab_force.argtypes = [hp, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L

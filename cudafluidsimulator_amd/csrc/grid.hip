@@ -78,6 +78,25 @@ void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                                                    pos_out, vel_out, cellRange, n);
 }
 
+__global__ void k_lower_bounds(const uint32_t *__restrict__ keys, int n, Thresholds thr,
+                               int nthr, int *__restrict__ out) {
+    int t = threadIdx.x;
+    if (t >= nthr) return;
+    uint32_t v = thr.v[t];
+    int lo = 0, hi = n; // first index with keys[idx] >= v
+    while (lo < hi) {
+        int mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    out[t] = lo;
+}
+
+void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr, int nthr,
+                             int *bounds_dev, hipStream_t s) {
+    k_lower_bounds<<<1, 64, 0, s>>>(sorted_keys, n, thr, nthr, bounds_dev);
+}
+
 // kernelMoveParticles (simulator.cu:329-367), launched <<<1, numCellsPerDim>>>
 // like the reference (simulator.cu:483-486): thread t owns z-layer
 // (int)((float)t*h/h).  Velocities are edited in the sorted stream through the

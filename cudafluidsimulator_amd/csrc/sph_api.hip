@@ -29,6 +29,13 @@ thread_local std::string g_create_error;
 
 constexpr int kEventRing = 64;
 
+struct PairEvent { // one timed section of the slab path
+    hipEvent_t a = nullptr, b = nullptr;
+    double *target = nullptr;
+    bool used = false;
+};
+constexpr int kPairRing = 48;
+
 struct StepEvents {
     hipEvent_t e[6]; // start, hash, sort, gather, density, force
     hipEvent_t c[2]; // copy start / end
@@ -62,6 +69,11 @@ struct sph_handle {
     int ringHead = 0;
     StepEvents *curEv = nullptr;
     SphKernelTimes kt{};
+    bool external = false;  // pos4/vel4 are caller-owned (sph_bind_buffers)
+    hipStream_t ownCompute = nullptr;
+    int *boundsDev = nullptr, *boundsHost = nullptr;
+    PairEvent pairs[kPairRing];
+    int pairHead = 0;
     bool ready = false;     // state uploaded
     bool gridValid = false; // sorted streams + cell table match `sorted`
     int phase = 0;          // 0 idle, 1 grid done, 2 density done, 3 force done
@@ -169,15 +181,19 @@ void init_positions_dense(const SphSettings &s, float *pos) {
 
 int alloc_device(sph_handle *h) {
     const size_t cap = (size_t)(h->cap > 0 ? h->cap : 1);
+    h->external = (h->opt.flags & SPH_FLAG_EXTERNAL_STATE) != 0;
+    const size_t posCap = h->external ? 1 : cap; // id-ordered read-back is single-domain only
     for (int b = 0; b < 2; ++b) {
-        HIPCHK(h, hipMalloc(&h->pos4[b], cap * sizeof(float4)));
-        HIPCHK(h, hipMalloc(&h->vel4[b], cap * sizeof(float4)));
+        if (!h->external) {
+            HIPCHK(h, hipMalloc(&h->pos4[b], cap * sizeof(float4)));
+            HIPCHK(h, hipMalloc(&h->vel4[b], cap * sizeof(float4)));
+            // never hand uninitialised indices to a gather, whatever happens upstream
+            HIPCHK(h, hipMemset(h->pos4[b], 0, cap * sizeof(float4)));
+            HIPCHK(h, hipMemset(h->vel4[b], 0, cap * sizeof(float4)));
+        }
         HIPCHK(h, hipMalloc(&h->ws.keys[b], cap * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->ws.vals[b], cap * sizeof(uint32_t)));
-        HIPCHK(h, hipMalloc(&h->devPos[b], cap * 3 * sizeof(float)));
-        // never hand uninitialised indices to a gather, whatever happens upstream
-        HIPCHK(h, hipMemset(h->pos4[b], 0, cap * sizeof(float4)));
-        HIPCHK(h, hipMemset(h->vel4[b], 0, cap * sizeof(float4)));
+        HIPCHK(h, hipMalloc(&h->devPos[b], posCap * 3 * sizeof(float)));
         HIPCHK(h, hipMemset(h->ws.keys[b], 0, cap * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->ws.vals[b], 0, cap * sizeof(uint32_t)));
         HIPCHK(h, hipEventCreateWithFlags(&h->computeDone[b], hipEventDisableTiming));
@@ -191,8 +207,14 @@ int alloc_device(sph_handle *h) {
     HIPCHK(h, hipMalloc(&h->ws.digitTotal, 256 * sizeof(uint32_t)));
     HIPCHK(h, hipMalloc(&h->cellRange, (size_t)h->P.numCells * sizeof(int2)));
     HIPCHK(h, hipMemset(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2)));
-    HIPCHK(h, hipHostMalloc(&h->hostPos, cap * 3 * sizeof(float), hipHostMallocDefault));
-    memset(h->hostPos, 0, cap * 3 * sizeof(float));
+    HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
+    memset(h->hostPos, 0, posCap * 3 * sizeof(float));
+    HIPCHK(h, hipMalloc(&h->boundsDev, 8 * sizeof(int)));
+    HIPCHK(h, hipHostMalloc(&h->boundsHost, 8 * sizeof(int), hipHostMallocDefault));
+    for (auto &pe : h->pairs) {
+        HIPCHK(h, hipEventCreate(&pe.a));
+        HIPCHK(h, hipEventCreate(&pe.b));
+    }
     if (h->opt.flags & SPH_FLAG_STORE_FORCE)
         HIPCHK(h, hipMalloc(&h->force4, cap * sizeof(float4)));
     HIPCHK(h, hipMalloc(&h->pairCounter, sizeof(unsigned long long)));
@@ -231,6 +253,7 @@ int resolve_events(sph_handle *h, StepEvents &se) {
 }
 
 int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
     if (n != h->n) return fail(h, SPH_EINVAL, "particle count differs from settings");
     const float hh = h->settings.h;
     const int D = h->P.D;
@@ -299,9 +322,132 @@ int begin_step_events(sph_handle *h) {
     return SPH_OK;
 }
 
+int resolve_pair(sph_handle *h, PairEvent &pe) {
+    if (!pe.used) return SPH_OK;
+    float ms = 0.f;
+    HIPCHK(h, hipEventSynchronize(pe.b));
+    HIPCHK(h, hipEventElapsedTime(&ms, pe.a, pe.b));
+    *pe.target += ms * 1e-3;
+    pe.used = false;
+    return SPH_OK;
+}
+
+// begin a timed section whose GPU time is added to *target when resolved
+int pair_begin(sph_handle *h, double *target, PairEvent **out) {
+    PairEvent &pe = h->pairs[h->pairHead];
+    int rc = resolve_pair(h, pe);
+    if (rc) return rc;
+    h->pairHead = (h->pairHead + 1) % kPairRing;
+    pe.target = target;
+    pe.used = true;
+    HIPCHK(h, hipEventRecord(pe.a, h->compute));
+    *out = &pe;
+    return SPH_OK;
+}
+
+int slab_range_ok(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
+    if (!h->external || !h->pos4[0]) return fail(h, SPH_ESTATE, "sph_bind_buffers first");
+    if ((buf != 0 && buf != 1) || i_begin < 0 || i_end < i_begin || n_all < i_end || n_all > h->cap)
+        return fail(h, SPH_EINVAL, "bad slab range");
+    return SPH_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int sph_set_stream(sph_handle *h, void *hip_stream) {
+    if (!h) return SPH_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->compute));
+    if (!h->ownCompute) h->ownCompute = h->compute;
+    h->compute = hip_stream ? (hipStream_t)hip_stream : h->ownCompute;
+    return SPH_OK;
+}
+
+int sph_bind_buffers(sph_handle *h, void *pos4_a, void *vel4_a, void *pos4_b, void *vel4_b,
+                     int capacity) {
+    if (!h) return SPH_EINVAL;
+    if (!h->external) return fail(h, SPH_ESTATE, "create with SPH_FLAG_EXTERNAL_STATE");
+    if (!pos4_a || !vel4_a || !pos4_b || !vel4_b || capacity > h->cap || capacity < 0)
+        return fail(h, SPH_EINVAL, "bad buffers / capacity exceeds options.capacity");
+    h->pos4[0] = (float4 *)pos4_a;
+    h->vel4[0] = (float4 *)vel4_a;
+    h->pos4[1] = (float4 *)pos4_b;
+    h->vel4[1] = (float4 *)vel4_b;
+    return SPH_OK;
+}
+
+int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
+                  const uint32_t *thresholds, int nthr, int32_t *bounds_out) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, src_buf, 0, 0, 0);
+    if (rc) return rc;
+    if (src_offset < 0 || count < 0 || (long long)src_offset + count > h->cap || nthr < 0 ||
+        nthr > 8 || (nthr > 0 && (!thresholds || !bounds_out)))
+        return fail(h, SPH_EINVAL, "bad sort range");
+    hipStream_t s = h->compute;
+    PairEvent *pe = nullptr;
+    if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
+    sph_launch_hash(h->P, h->pos4[src_buf] + src_offset, h->ws.keys[0], h->ws.vals[0], count, s);
+    int res = sph_sort_pairs(h->ws, count, key_bits(h), s);
+    sph_launch_gather(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
+                      h->ws.vals[res], h->ws.keys[res], h->pos4[src_buf ^ 1],
+                      h->vel4[src_buf ^ 1], h->cellRange, count, s);
+    HIPCHK(h, hipEventRecord(pe->b, s));
+    if (nthr > 0) {
+        Thresholds T{};
+        for (int k = 0; k < nthr; ++k) T.v[k] = thresholds[k];
+        sph_launch_lower_bounds(h->ws.keys[res], count, T, nthr, h->boundsDev, s);
+        HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int),
+                                 hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
+    }
+    HIPCHK(h, hipGetLastError());
+    h->sorted = src_buf ^ 1;
+    h->sortedKeyBuf = res;
+    h->gridValid = true;
+    return SPH_OK;
+}
+
+int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
+    if (rc) return rc;
+    if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
+    SweepArgs A = make_sweep_args(h);
+    A.i_begin = i_begin;
+    A.i_end = i_end;
+    A.n_all = n_all;
+    A.force_out = nullptr;
+    if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
+    PairEvent *pe = nullptr;
+    if ((rc = pair_begin(h, &h->kt.density, &pe))) return rc;
+    sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
+    HIPCHK(h, hipEventRecord(pe->b, h->compute));
+    HIPCHK(h, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
+    if (rc) return rc;
+    if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
+    SweepArgs A = make_sweep_args(h);
+    A.i_begin = i_begin;
+    A.i_end = i_end;
+    A.n_all = n_all;
+    A.force_out = nullptr;
+    PairEvent *pe = nullptr;
+    if ((rc = pair_begin(h, &h->kt.force, &pe))) return rc;
+    sph_launch_force(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
+    HIPCHK(h, hipEventRecord(pe->b, h->compute));
+    HIPCHK(h, hipGetLastError());
+    h->kt.steps += 1;
+    return SPH_OK;
+}
 
 const char *sph_build_info(void) {
     return "libsph_hip gfx950 (MI355X/CDNA4), api v1, strict-fp32 sweeps, "
@@ -384,8 +530,8 @@ void sph_destroy(sph_handle *h) {
     if (h->compute) (void)hipStreamSynchronize(h->compute);
     if (h->copy) (void)hipStreamSynchronize(h->copy);
     for (int b = 0; b < 2; ++b) {
-        if (h->pos4[b]) (void)hipFree(h->pos4[b]);
-        if (h->vel4[b]) (void)hipFree(h->vel4[b]);
+        if (h->pos4[b] && !h->external) (void)hipFree(h->pos4[b]);
+        if (h->vel4[b] && !h->external) (void)hipFree(h->vel4[b]);
         if (h->ws.keys[b]) (void)hipFree(h->ws.keys[b]);
         if (h->ws.vals[b]) (void)hipFree(h->ws.vals[b]);
         if (h->devPos[b]) (void)hipFree(h->devPos[b]);
@@ -403,6 +549,13 @@ void sph_destroy(sph_handle *h) {
         for (auto &e : se.e) if (e) (void)hipEventDestroy(e);
         for (auto &e : se.c) if (e) (void)hipEventDestroy(e);
     }
+    if (h->boundsDev) (void)hipFree(h->boundsDev);
+    if (h->boundsHost) (void)hipHostFree(h->boundsHost);
+    for (auto &pe : h->pairs) {
+        if (pe.a) (void)hipEventDestroy(pe.a);
+        if (pe.b) (void)hipEventDestroy(pe.b);
+    }
+    if (h->ownCompute) h->compute = h->ownCompute;
     if (h->compute) (void)hipStreamDestroy(h->compute);
     if (h->copy) (void)hipStreamDestroy(h->copy);
     delete h;
@@ -516,14 +669,9 @@ int sph_step(sph_handle *h, SphTimes *times) {
     if (!h) return SPH_EINVAL;
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
     int rc;
-    double waited = 0.0;
-    if (times) {
-        // "Data transfer" = the part of the previous step's D2H the pipeline
-        // could not hide (the reference blocks for the whole copy instead).
-        auto t0 = std::chrono::steady_clock::now();
-        HIPCHK(h, hipStreamSynchronize(h->copy));
-        waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    }
+    // slot of the PREVIOUS step's position copy (if any)
+    const int prevSlot = (int)((h->stepIndex + 1) & 1);
+    const bool prevCopy = h->stepIndex > 0 && h->copyPending[prevSlot];
     if ((rc = begin_step_events(h))) return rc;
     StepEvents *ev = h->curEv;
     if ((rc = sph_phase_grid(h))) return rc;
@@ -538,7 +686,15 @@ int sph_step(sph_handle *h, SphTimes *times) {
         HIPCHK(h, hipEventElapsedTime(&sphMs, ev->e[3], ev->e[5]));
         times->buildGrid += gridMs * 1e-3;
         times->sphUpdate += sphMs * 1e-3;
-        times->memcpy += waited;
+        // "Data transfer" = the part of the previous step's D2H that this
+        // step's compute did not hide (the reference blocks on every copy,
+        // simulator.cu:532-533; here step k's copy overlaps step k+1).
+        if (prevCopy) {
+            auto t0 = std::chrono::steady_clock::now();
+            HIPCHK(h, hipEventSynchronize(h->copyDone[prevSlot]));
+            times->memcpy +=
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
         times->iters += 1;
     }
     return SPH_OK;
@@ -643,6 +799,8 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     if (rc) return rc;
     for (auto &se : h->ring)
         if ((rc = resolve_events(h, se))) return rc;
+    for (auto &pe : h->pairs)
+        if ((rc = resolve_pair(h, pe))) return rc;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) {
         HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, sizeof(unsigned long long), hipMemcpyDeviceToHost));
         h->kt.pair_tests = *h->pairHost;

@@ -64,6 +64,10 @@ void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                        const uint32_t *perm, const uint32_t *sorted_keys,
                        float4 *pos_out, float4 *vel_out, int2 *cellRange, int n,
                        hipStream_t s);
+// bounds[k] = #keys < thr[k] over sorted keys (one binary search per lane)
+struct Thresholds { uint32_t v[8]; };
+void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr, int nthr,
+                             int *bounds_dev, hipStream_t s);
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4,
                       int mx, int my, hipStream_t s);
 

@@ -65,7 +65,10 @@ enum {
 enum {
     SPH_FLAG_COUNT_PAIRS = 1, /* accumulate the candidate pair-test count per step */
     SPH_FLAG_STORE_FORCE = 2, /* keep per-particle force of the last step (tests)  */
-    SPH_FLAG_NO_READBACK = 4  /* skip the per-step D2H of positions (kernel studies) */
+    SPH_FLAG_NO_READBACK = 4, /* skip the per-step D2H of positions (kernel studies) */
+    SPH_FLAG_EXTERNAL_STATE = 8 /* particle streams are caller-owned device buffers
+                                   (sph_bind_buffers); used by the multi-GPU slab
+                                   driver so halo send/recv is zero-copy */
 };
 
 typedef struct SphOptions {
@@ -143,6 +146,28 @@ int sph_phase_readback(sph_handle *h); /* the per-step D2H (simulator.cu:479) */
  * n (key, index) pairs; writes the permutation (host pointers). */
 int sph_sort_check(int device, const uint32_t *keys, int n, int key_bits,
                    uint32_t *perm_out, uint32_t *sorted_keys_out);
+
+/* ---- z-slab decomposition (one handle per GPU; cudafluidsimulator_amd/slab.py) ----
+ * No reference counterpart: the reference is single-GPU.  The slab
+ * driver owns four float4 device buffers per rank -- pos4[2], vel4[2], `capacity`
+ * particles each -- and exchanges halo / migrant ranges of them with RCCL
+ * send/recv; the library only runs kernels on ranges of those buffers, on the
+ * caller's stream (so it is stream-ordered with the collectives). */
+int sph_set_stream(sph_handle *h, void *hip_stream); /* NULL = handle's own stream */
+int sph_bind_buffers(sph_handle *h, void *pos4_a, void *vel4_a, void *pos4_b,
+                     void *vel4_b, int capacity);
+/* Hash + stable radix sort + gather of particles [src_offset, src_offset+count)
+ * of buffer pair `src_buf` into [0, count) of the other pair, and the cell table
+ * over the result.  bounds_out[k] = number of sorted keys < thresholds[k]
+ * (k < nthr <= 8); blocks until those counts are on the host. */
+int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
+                  const uint32_t *thresholds, int nthr, int32_t *bounds_out);
+/* kernelUpdatePressureAndDensity for particles [i_begin, i_end) of the n_all
+ * sorted particles in buffer pair `buf` (halo particles are candidates only). */
+int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all);
+/* kernelUpdateForces + kernelUpdatePositions for [i_begin, i_end); new state is
+ * written to the same indices of the other buffer pair. */
+int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all);
 
 const char *sph_build_info(void);
 
