@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sph_get_kernel_times", "sph_last_error", "sph_phase_grid", "sph_phase_density",
     "sph_phase_force", "sph_phase_readback", "sph_sort_check", "sph_build_info",
     "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_density",
-    "sph_slab_force",
+    "sph_slab_force", "sph_initial_positions",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library():
     i32p = C.POINTER(C.c_int32)
     hp = C.c_void_p
     L.sph_default_settings.argtypes = [C.POINTER(SphSettings), C.c_int, C.c_int]
+    L.sph_initial_positions.argtypes = [C.POINTER(SphSettings), fp]
     L.sph_create.argtypes = [C.POINTER(SphSettings), C.POINTER(SphOptions), C.POINTER(hp)]
     L.sph_destroy.argtypes = [hp]
     L.sph_destroy.restype = None

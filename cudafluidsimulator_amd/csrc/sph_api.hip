@@ -474,6 +474,20 @@ int sph_default_settings(SphSettings *out, int numParticles, int randomInit) {
     return SPH_OK;
 }
 
+int sph_initial_positions(const SphSettings *settings, float *pos_xyz) {
+    if (!settings || (!pos_xyz && settings->numParticles > 0) || settings->numParticles < 0)
+        return SPH_EINVAL;
+    int written = init_positions_reference(*settings, pos_xyz);
+    if (written < settings->numParticles) {
+        fprintf(stderr,
+                "sph: -i grid holds at most %d lattice points in the reference "
+                "(simulator.cu:439-452); n=%d uses the dense-lattice EXTENSION\n",
+                written, settings->numParticles);
+        init_positions_dense(*settings, pos_xyz);
+    }
+    return SPH_OK;
+}
+
 int sph_create(const SphSettings *settings, const SphOptions *options, sph_handle **out) {
     if (!settings || !out) return fail(nullptr, SPH_EINVAL, "null argument");
     *out = nullptr;
@@ -565,14 +579,8 @@ int sph_setup(sph_handle *h) {
     if (!h) return SPH_EINVAL;
     const int n = h->n;
     std::vector<float> pos((size_t)(n > 0 ? n : 1) * 3, 0.f);
-    int written = init_positions_reference(h->settings, pos.data());
-    if (written < n) {
-        fprintf(stderr,
-                "sph: -i grid holds at most %d lattice points in the reference "
-                "(simulator.cu:439-452); n=%d uses the dense-lattice EXTENSION\n",
-                written, n);
-        init_positions_dense(h->settings, pos.data());
-    }
+    int rc = sph_initial_positions(&h->settings, pos.data());
+    if (rc) return fail(h, rc, "sph_initial_positions failed");
     return upload_common(h, pos.data(), nullptr, n);
 }
 

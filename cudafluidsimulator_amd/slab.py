@@ -1,0 +1,426 @@
+"""z-slab decomposition of the SPH step across GPUs (one process per GPU).
+
+The reference is single-GPU; this is new design.  The box is cut
+into slabs of whole cell layers along z -- z is the slowest digit of the
+flattened cell key (simulator.cu:78-82), so a slab is a contiguous range of the
+key-sorted particle streams, gravity (y) does not drain slabs, and halo layers
+are contiguous too.  Support radius = cell size, so the halo is ONE layer.
+
+Per step and rank (buffers: pos4[2], vel4[2]; `s` sorted, `t` the other pair):
+
+  1. sort own particles by cell key            -> [mig_dn|bnd_lo|interior|bnd_hi|mig_up]
+  2. exchange counts, then (RCCL send/recv)    : migrants (pos+vel) and boundary
+                                                 layers (pos+vel) to both neighbours
+  3. assemble t = [H_lo | my mig_dn | R_lo | stay | R_hi | my mig_up | H_hi]
+     and sort it again (stable)                -> [halo_lo | owned | halo_hi] + cell table
+  4. density for owned; exchange vel4 (carries rho) of the boundary layers
+  5. force + integrate for owned               -> new owned state in t
+
+Why that concatenation order: the canonical summation order (oracle) is the
+stable sort of the previous GLOBAL order, which is rank order (z-major keys).
+Particles arriving from below must therefore precede, and particles from above
+follow, the local ones inside a cell; a neighbour's halo cells must list that
+neighbour's stayers before (upper halo: after) the particles I just sent it.
+With this order N slabs reproduce the single-domain result BIT FOR BIT.
+
+The driver is transport- and backend-agnostic: `DistTransport` uses
+torch.distributed P2P (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPU);
+`run_loopback` steps several slabs inside one process.  The compute backend is
+`HipSlabBackend` (libsph_hip.so through the C-ABI); tests inject a CPU backend.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SphError, SphKernelTimes, SphOptions, load_library
+
+
+# --------------------------------------------------------------------------
+# geometry
+# --------------------------------------------------------------------------
+def partition_layers(layer_hist, world, min_layers=2):
+    """Cut D cell layers into `world` contiguous slabs with ~equal particle
+    counts (cuts on layer boundaries, every slab >= min_layers thick)."""
+    hist = np.asarray(layer_hist, dtype=np.int64)
+    D = len(hist)
+    if world * min_layers > D:
+        raise ValueError("too many slabs for the grid")
+    cum = np.concatenate([[0], np.cumsum(hist)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        z = int(np.searchsorted(cum, target, side="left"))
+        if z > 0 and abs(cum[z - 1] - target) <= abs(cum[min(z, D)] - target):
+            z -= 1
+        z = max(z, cuts[-1] + min_layers)
+        z = min(z, D - (world - r) * min_layers)
+        cuts.append(z)
+    cuts.append(D)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def layer_of(pos_z, h, D):
+    """Cell layer exactly as getGridCell computes it (fp32 divide, truncate)."""
+    c = (np.asarray(pos_z, np.float32) / np.float32(h)).astype(np.float32).astype(np.int64)
+    return np.clip(c, 0, D - 1)
+
+
+# --------------------------------------------------------------------------
+# compute backend over the C-ABI
+# --------------------------------------------------------------------------
+class HipSlabBackend:
+    """Kernels of libsph_hip.so on ranges of four torch-owned float4 buffers."""
+
+    def __init__(self, settings, capacity, device=0, sweep="lds", flags=0):
+        self.settings = settings
+        self.cap = int(capacity)
+        self.device = torch.device("cuda", device)
+        self._L = load_library()
+        torch.cuda.set_device(self.device)
+        self.pos = [torch.zeros((self.cap, 4), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.vel = [torch.zeros((self.cap, 4), dtype=torch.float32, device=self.device) for _ in range(2)]
+        opt = SphOptions()
+        opt.struct_size = C.sizeof(SphOptions)
+        opt.device = device
+        opt.math_mode = _lib.SPH_MATH_STRICT
+        opt.sweep = _lib.SPH_SWEEP_DIRECT if sweep == "direct" else _lib.SPH_SWEEP_LDS
+        opt.flags = flags | _lib.SPH_FLAG_EXTERNAL_STATE | _lib.SPH_FLAG_NO_READBACK
+        opt.capacity = self.cap
+        self._h = C.c_void_p()
+        rc = self._L.sph_create(C.byref(settings), C.byref(opt), C.byref(self._h))
+        if rc:
+            raise SphError(f"sph_create failed ({rc}): {self._L.sph_last_error(None).decode()}")
+        self._check(self._L.sph_bind_buffers(self._h, self.pos[0].data_ptr(), self.vel[0].data_ptr(),
+                                             self.pos[1].data_ptr(), self.vel[1].data_ptr(),
+                                             self.cap), "sph_bind_buffers")
+        # run on torch's current stream: stream-ordered with the RCCL send/recv
+        self._check(self._L.sph_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "sph_set_stream")
+
+    def _check(self, rc, what):
+        if rc:
+            raise SphError(f"{what} failed ({rc}): {self._L.sph_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            torch.cuda.synchronize(self.device)
+            self._L.sph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def sort(self, src_buf, offset, count, thresholds):
+        thr = (C.c_uint32 * len(thresholds))(*[int(t) for t in thresholds])
+        out = (C.c_int32 * len(thresholds))()
+        self._check(self._L.sph_slab_sort(self._h, src_buf, offset, count, thr, len(thresholds), out),
+                    "sph_slab_sort")
+        return list(out)
+
+    def density(self, buf, i0, i1, n_all):
+        self._check(self._L.sph_slab_density(self._h, buf, i0, i1, n_all), "sph_slab_density")
+
+    def force(self, buf, i0, i1, n_all):
+        self._check(self._L.sph_slab_force(self._h, buf, i0, i1, n_all), "sph_slab_force")
+
+    def kernel_times(self, reset=False):
+        kt = SphKernelTimes()
+        self._check(self._L.sph_get_kernel_times(self._h, C.byref(kt), 1 if reset else 0),
+                    "sph_get_kernel_times")
+        return kt
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+# --------------------------------------------------------------------------
+# one slab's state machine (no communication inside)
+# --------------------------------------------------------------------------
+DOWN, UP = -1, +1
+
+
+class Slab:
+    def __init__(self, backend, rank, world, zlo, zhi, D):
+        self.b = backend
+        self.rank, self.world = rank, world
+        self.zlo, self.zhi, self.D = zlo, zhi, D
+        self.has_dn, self.has_up = rank > 0, rank < world - 1
+        if (self.has_dn or self.has_up) and zhi - zlo < 2:
+            raise ValueError("a slab needs at least two cell layers")
+        DD = D * D
+        self.thr = [zlo * DD, (zlo + 1) * DD, (zhi - 1) * DD, zhi * DD]
+        self.cur, self.off, self.n_own = 0, 0, 0
+        self.seg = None
+        self.steps = 0
+
+    # ---- initial state: owned particles in particle-id order ----
+    def load(self, pos4, vel4):
+        n = len(pos4)
+        if n > self.b.cap:
+            raise ValueError("slab capacity too small")
+        self.cur, self.off, self.n_own = 0, 0, n
+        self.b.pos[0][:n].copy_(pos4)
+        self.b.vel[0][:n].copy_(vel4)
+
+    def owned(self):
+        """(pos4, vel4) views of the owned particles (sorted order of the last step)."""
+        a, b = self.off, self.off + self.n_own
+        return self.b.pos[self.cur][a:b], self.b.vel[self.cur][a:b]
+
+    # ---- phase 1: local sort; returns the counts both neighbours need ----
+    def local_sort(self):
+        n = self.n_own
+        b0, b1, b2, b3 = self.b.sort(self.cur, self.off, n, self.thr)
+        if not self.has_dn:
+            assert b0 == 0
+        if not self.has_up:
+            assert b3 == n
+        self.s = self.cur ^ 1
+        self.seg = (b0, b1, b2, b3, n)
+        to_dn = [b0, b1 - b0] if self.has_dn else None      # [migrants, boundary layer]
+        to_up = [n - b3, b3 - b2] if self.has_up else None
+        return to_dn, to_up
+
+    # ---- phase 2: plan exchange A given the neighbours' counts ----
+    def plan_exchange_a(self, from_dn, from_up):
+        b0, b1, b2, b3, n = self.seg
+        mig_from_dn, bnd_from_dn = from_dn if self.has_dn else (0, 0)
+        mig_from_up, bnd_from_up = from_up if self.has_up else (0, 0)
+        s, t = self.s, self.s ^ 1
+        P, V = self.b.pos, self.b.vel
+        # t = [H_lo | my mig_dn | R_lo | stay | R_hi | my mig_up | H_hi]
+        o = [0]
+        for c in (bnd_from_dn, b0, mig_from_dn, b3 - b0, mig_from_up, n - b3, bnd_from_up):
+            o.append(o[-1] + c)
+        self.n_comb = o[-1]
+        if self.n_comb > self.b.cap:
+            raise SphError("slab capacity exceeded by halo + migrants")
+        self.halo_lo_expected = bnd_from_dn + b0
+        self.halo_hi_expected = bnd_from_up + (n - b3)
+        for A in (P, V):
+            if b0:
+                A[t][o[1]:o[2]].copy_(A[s][0:b0])
+            if b3 - b0:
+                A[t][o[3]:o[4]].copy_(A[s][b0:b3])
+            if n - b3:
+                A[t][o[5]:o[6]].copy_(A[s][b3:n])
+        sends, recvs = [], []
+        if self.has_dn:   # message order (both sides): boundary layer first, then migrants
+            for A in (P, V):
+                sends.append((DOWN, A[s][b0:b1]))
+            for A in (P, V):
+                sends.append((DOWN, A[s][0:b0]))
+            for A in (P, V):
+                recvs.append((DOWN, A[t][o[0]:o[1]]))
+            for A in (P, V):
+                recvs.append((DOWN, A[t][o[2]:o[3]]))
+        if self.has_up:
+            for A in (P, V):
+                sends.append((UP, A[s][b2:b3]))
+            for A in (P, V):
+                sends.append((UP, A[s][b3:n]))
+            for A in (P, V):
+                recvs.append((UP, A[t][o[6]:o[7]]))
+            for A in (P, V):
+                recvs.append((UP, A[t][o[4]:o[5]]))
+        return sends, recvs
+
+    # ---- phase 3: sort the combined array, density, plan exchange B ----
+    def combined_sort_and_density(self):
+        t = self.s ^ 1
+        i0, e_lo, s_hi, i1 = self.b.sort(t, 0, self.n_comb, self.thr)
+        self.s = t ^ 1
+        if i0 != self.halo_lo_expected or self.n_comb - i1 != self.halo_hi_expected:
+            raise SphError(f"rank {self.rank}: halo layers hold particles of other layers "
+                           f"({i0} vs {self.halo_lo_expected}, {self.n_comb - i1} vs "
+                           f"{self.halo_hi_expected}): a particle crossed more than one cell in z")
+        self.rng = (i0, e_lo, s_hi, i1)
+        self.b.density(self.s, i0, i1, self.n_comb)
+        V = self.b.vel[self.s]
+        sends, recvs = [], []
+        if self.has_dn:
+            sends.append((DOWN, V[i0:e_lo]))
+            recvs.append((DOWN, V[0:i0]))
+        if self.has_up:
+            sends.append((UP, V[s_hi:i1]))
+            recvs.append((UP, V[i1:self.n_comb]))
+        return sends, recvs
+
+    # ---- phase 4: force + integrate for the owned range ----
+    def force(self):
+        i0, _, _, i1 = self.rng
+        self.b.force(self.s, i0, i1, self.n_comb)
+        self.cur, self.off, self.n_own = self.s ^ 1, i0, i1 - i0
+        self.steps += 1
+
+
+# --------------------------------------------------------------------------
+# transports
+# --------------------------------------------------------------------------
+def _nonempty(msgs):
+    return [(d, x) for d, x in msgs if x.numel() > 0]
+
+
+class DistTransport:
+    """torch.distributed point-to-point: backend 'nccl' (= RCCL over xGMI) for
+    CUDA tensors, 'gloo' for CPU tensors.  Chain topology: rank r talks to r-1
+    and r+1 only; no collective is needed on the data path."""
+
+    def __init__(self, dist, rank, world, device, group=None):
+        self.dist, self.rank, self.world, self.device, self.group = dist, rank, world, device, group
+
+    def exchange_counts(self, to_dn, to_up):
+        dist = self.dist
+        ops, bufs = [], {}
+        for d, payload in ((DOWN, to_dn), (UP, to_up)):
+            if payload is None:
+                continue
+            peer = self.rank + d
+            snd = torch.tensor(payload, dtype=torch.int64, device=self.device)
+            rcv = torch.zeros(len(payload), dtype=torch.int64, device=self.device)
+            bufs[d] = (snd, rcv)
+            ops.append(dist.P2POp(dist.isend, snd, peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, rcv, peer, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        out = {d: bufs[d][1].tolist() for d in bufs}
+        return out.get(DOWN), out.get(UP)
+
+    def exchange(self, sends, recvs):
+        dist = self.dist
+        ops = []
+        for d, x in _nonempty(sends):
+            ops.append(dist.P2POp(dist.isend, x, self.rank + d, group=self.group))
+        for d, x in _nonempty(recvs):
+            ops.append(dist.P2POp(dist.irecv, x, self.rank + d, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+
+def step_distributed(slab, tr):
+    """One step of this rank's slab over a DistTransport."""
+    to_dn, to_up = slab.local_sort()
+    from_dn, from_up = tr.exchange_counts(to_dn, to_up)
+    # a neighbour sends [migrants, boundary]; from below the migrants are its
+    # mig_up / boundary its bnd_hi, from above its mig_dn / bnd_lo
+    sends, recvs = slab.plan_exchange_a(from_dn, from_up)
+    tr.exchange(sends, recvs)
+    sends, recvs = slab.combined_sort_and_density()
+    tr.exchange(sends, recvs)
+    slab.force()
+
+
+def run_loopback(slabs, steps):
+    """Step several slabs of ONE process in lock-step (1-GPU / CPU testing):
+    messages are delivered by tensor copies in the same order DistTransport
+    would deliver them."""
+    def deliver(all_sends, all_recvs):
+        for r, slab_sends in enumerate(all_sends):
+            for d in (DOWN, UP):
+                out = [x for dd, x in _nonempty(slab_sends) if dd == d]
+                if not out:
+                    continue
+                peer = r + d
+                inn = [x for dd, x in _nonempty(all_recvs[peer]) if dd == -d]
+                assert len(out) == len(inn), "send/recv plans disagree"
+                for src, dst in zip(out, inn):
+                    assert src.shape == dst.shape, (src.shape, dst.shape)
+                    dst.copy_(src)
+
+    for _ in range(steps):
+        counts = [s.local_sort() for s in slabs]
+        plans = []
+        for r, s in enumerate(slabs):
+            from_dn = counts[r - 1][1] if r > 0 else None
+            from_up = counts[r + 1][0] if r + 1 < len(slabs) else None
+            plans.append(s.plan_exchange_a(from_dn, from_up))
+        deliver([p[0] for p in plans], [p[1] for p in plans])
+        plans = [s.combined_sort_and_density() for s in slabs]
+        deliver([p[0] for p in plans], [p[1] for p in plans])
+        for s in slabs:
+            s.force()
+
+
+# --------------------------------------------------------------------------
+# initial condition split + bench entry
+# --------------------------------------------------------------------------
+def make_initial(settings):
+    """Host arrays pos4 (id bits in .w) / vel4 of the reference initialiser."""
+    import ctypes
+    n = settings.numParticles
+    pos = np.zeros((n, 3), np.float32)
+    rc = load_library().sph_initial_positions(ctypes.byref(settings),
+                                              pos.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    if rc:
+        raise SphError("sph_initial_positions failed")
+    return pack_state(pos, None)
+
+
+def pack_state(pos, vel, ids=None):
+    n = len(pos)
+    pos4 = np.zeros((n, 4), np.float32)
+    pos4[:, :3] = pos
+    pos4[:, 3] = (np.arange(n, dtype=np.uint32) if ids is None else np.asarray(ids, np.uint32)).view(np.float32)
+    vel4 = np.zeros((n, 4), np.float32)
+    if vel is not None:
+        vel4[:, :3] = vel
+    return pos4, vel4
+
+
+def split_initial(pos4, vel4, h, D, world):
+    """Static slab bounds from the z-layer histogram and each rank's particles."""
+    layers = layer_of(pos4[:, 2], h, D)
+    bounds = partition_layers(np.bincount(layers, minlength=D), world)
+    parts = []
+    for zlo, zhi in bounds:
+        m = (layers >= zlo) & (layers < zhi)
+        parts.append((np.ascontiguousarray(pos4[m]), np.ascontiguousarray(vel4[m])))
+    return bounds, parts
+
+
+def run_slab_bench(args, dist, rank, world, local_rank):
+    """bench.py's N>1 leg: strong scaling of one n-particle domain over `world`
+    GPUs.  Returns rank-local timing; bench.py takes the max over ranks."""
+    from .simulator import default_settings
+    n = args.particles
+    settings = default_settings(n, args.init == "random")
+    D = int(settings.numCellsPerDim)
+    pos4, vel4 = make_initial(settings)
+    bounds, parts = split_initial(pos4, vel4, settings.h, D, world)
+    zlo, zhi = bounds[rank]
+    my_pos, my_vel = parts[rank]
+    cap = int(max(len(p[0]) for p in parts) * 1.6) + 65536
+    backend = HipSlabBackend(settings, cap, device=local_rank, sweep=args.sweep,
+                             flags=_lib.SPH_FLAG_COUNT_PAIRS)
+    slab = Slab(backend, rank, world, zlo, zhi, D)
+    tr = DistTransport(dist, rank, world, backend.device)
+    host = torch.empty((cap, 4), dtype=torch.float32).pin_memory()
+
+    def reload():
+        slab.load(torch.from_numpy(my_pos).to(backend.device), torch.from_numpy(my_vel).to(backend.device))
+
+    def one_step():
+        step_distributed(slab, tr)
+        p, _ = slab.owned()
+        host[:len(p)].copy_(p, non_blocking=True)   # per-step position read-back (simulator.cu:479)
+
+    reload()
+    for _ in range(args.warmup):
+        one_step()
+    reload()
+    backend.kernel_times(reset=True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kt = backend.kernel_times()
+    n_local = slab.n_own
+    backend.close()
+    return dict(elapsed=elapsed, kt=kt, n_total=n, n_local=n_local)

@@ -94,6 +94,11 @@ typedef struct sph_handle sph_handle;
 /* main.cpp:57-63 -- the constants main() derives before constructing Settings. */
 int sph_default_settings(SphSettings *out, int numParticles, int randomInit);
 
+/* The host half of Simulator::setup (simulator.cu:430-453) on its own: fills
+ * numParticles x (x,y,z) with the reference initial condition.  Needs no GPU
+ * (the slab driver splits this array across ranks). */
+int sph_initial_positions(const SphSettings *settings, float *pos_xyz);
+
 /* Simulator::Simulator (simulator.cu:370-375).  Copies *settings. */
 int sph_create(const SphSettings *settings, const SphOptions *options,
                sph_handle **out);

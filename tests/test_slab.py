@@ -1,0 +1,176 @@
+"""Multi-slab path: N z-slabs must reproduce the single-domain result BIT FOR
+BIT (canonical order is preserved across migration and halo merge).
+CPU: the slab driver (product code) over an oracle-backed compute backend, in
+one process (loopback) and over torch.distributed gloo with world_size 2 and 3.
+GPU: the same driver over libsph_hip.so, several slabs on one device."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cudafluidsimulator_amd as sph
+from cudafluidsimulator_amd import slab as S
+from helpers import assert_bit_equal
+from oracle import oracle as O
+from slab_backend_oracle import OracleSlabBackend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def moving_state(n, seed):
+    """Random fluid with z-velocities up to ~0.9 cell/step so particles migrate
+    between slabs every step (and bounce off the z walls)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(0.5, 9.5, (n, 3)).astype(np.float32)
+    vel = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    vel[:, 2] = rng.uniform(-9, 9, n).astype(np.float32)
+    return pos, vel
+
+
+def reference_run(pos, vel, steps):
+    ref = O.OracleSim(len(pos), False)
+    ref.upload(pos, vel)
+    ref.step(steps)
+    return ref.download()
+
+
+def collect(slabs_or_parts, n):
+    pos = np.full((n, 3), np.nan, np.float32)
+    vel = np.full((n, 3), np.nan, np.float32)
+    rho = np.full(n, np.nan, np.float32)
+    seen = 0
+    for p4, v4 in slabs_or_parts:
+        p4 = np.asarray(p4); v4 = np.asarray(v4)
+        ids = np.ascontiguousarray(p4[:, 3]).view(np.uint32)
+        pos[ids] = p4[:, :3]; vel[ids] = v4[:, :3]; rho[ids] = v4[:, 3]
+        seen += len(ids)
+    assert seen == n and not np.isnan(pos).any()
+    return pos, vel, rho
+
+
+def test_partition_layers():
+    hist = np.zeros(100, int); hist[10:90] = 1000
+    b = S.partition_layers(hist, 8)
+    assert b[0][0] == 0 and b[-1][1] == 100 and all(b[i][1] == b[i + 1][0] for i in range(7))
+    counts = [hist[a:c].sum() for a, c in b]
+    assert max(counts) - min(counts) <= 1000
+    with pytest.raises(ValueError):
+        S.partition_layers(hist, 60)
+    lopsided = np.zeros(100, int); lopsided[50] = 10
+    b = S.partition_layers(lopsided, 4)
+    assert all(c - a >= 2 for a, c in b)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_loopback_slabs_equal_single_domain_cpu(world):
+    n, steps = 6000, 12
+    pos, vel = moving_state(n, 21)
+    settings = sph.default_settings(n, False)
+    p4, v4 = S.pack_state(pos, vel)
+    bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+    slabs = []
+    for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
+        sl = S.Slab(OracleSlabBackend(settings, n), r, world, zlo, zhi, 100)
+        sl.load(torch.from_numpy(pp), torch.from_numpy(vv))
+        slabs.append(sl)
+    S.run_loopback(slabs, steps)
+    got = collect([tuple(x.numpy() for x in sl.owned()) for sl in slabs], n)
+    want = reference_run(pos, vel, steps)
+    assert_bit_equal(got[0], want["pos"], "pos")
+    assert_bit_equal(got[1], want["vel"], "vel")
+    assert_bit_equal(got[2], want["rho"], "rho")
+    # migration really happened
+    assert sum(sl.n_own for sl in slabs) == n
+    assert any(sl.n_own != len(parts[i][0]) for i, sl in enumerate(slabs))
+
+
+def _gloo_worker(rank, world, port, n, steps, seed, outdir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel = moving_state(n, seed)
+    settings = sph.default_settings(n, False)
+    p4, v4 = S.pack_state(pos, vel)
+    bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+    sl = S.Slab(OracleSlabBackend(settings, n), rank, world, *bounds[rank], 100)
+    sl.load(torch.from_numpy(parts[rank][0]), torch.from_numpy(parts[rank][1]))
+    tr = S.DistTransport(dist, rank, world, torch.device("cpu"))
+    for _ in range(steps):
+        S.step_distributed(sl, tr)
+    p, v = sl.owned()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), pos4=p.numpy(), vel4=v.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_slabs_equal_single_domain(world, tmp_path):
+    import torch.multiprocessing as mp
+    n, steps, seed = 4000, 10, 33
+    port = 29600 + world + (os.getpid() % 200)
+    mp.spawn(_gloo_worker, args=(world, port, n, steps, seed, str(tmp_path)), nprocs=world, join=True)
+    parts = []
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        parts.append((d["pos4"], d["vel4"]))
+    got = collect(parts, n)
+    pos, vel = moving_state(n, seed)
+    want = reference_run(pos, vel, steps)
+    assert_bit_equal(got[0], want["pos"], "pos")
+    assert_bit_equal(got[1], want["vel"], "vel")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_loopback_slabs_equal_single_domain(world):
+    n, steps = 60000, 8
+    pos, vel = moving_state(n, 5)
+    settings = sph.default_settings(n, False)
+    p4, v4 = S.pack_state(pos, vel)
+    bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+    slabs = []
+    for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
+        sl = S.Slab(S.HipSlabBackend(settings, n, device=0), r, world, zlo, zhi, 100)
+        sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
+        slabs.append(sl)
+    S.run_loopback(slabs, steps)
+    got = collect([tuple(x.cpu().numpy() for x in sl.owned()) for sl in slabs], n)
+    want = reference_run(pos, vel, steps)
+    assert_bit_equal(got[0], want["pos"], "pos")
+    assert_bit_equal(got[1], want["vel"], "vel")
+    assert_bit_equal(got[2], want["rho"], "rho")
+    # and against the single-domain HIP path
+    sim = sph.Simulator(settings)
+    sim.upload_state(pos, vel)
+    for _ in range(steps):
+        sim.simulate()
+    assert_bit_equal(got[0], sim.download_state()["pos"], "vs single-domain HIP")
+    sim.close()
+    for sl in slabs:
+        sl.b.close()
+
+
+@pytest.mark.gpu
+def test_hip_slab_reference_initialiser_4_slabs():
+    n, steps, world = 262144, 6, 4
+    settings = sph.default_settings(n, True)
+    p4, v4 = S.make_initial(settings)
+    bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+    slabs = []
+    for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
+        sl = S.Slab(S.HipSlabBackend(settings, n, device=0), r, world, zlo, zhi, 100)
+        sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
+        slabs.append(sl)
+    S.run_loopback(slabs, steps)
+    got = collect([tuple(x.cpu().numpy() for x in sl.owned()) for sl in slabs], n)
+    sim = sph.Simulator(settings)
+    sim.setup()
+    for _ in range(steps):
+        sim.simulate()
+    assert_bit_equal(got[0], sim.download_state()["pos"], "slabs vs single domain")
+    sim.close()
+    for sl in slabs:
+        sl.b.close()
