@@ -360,7 +360,9 @@ int sph_set_stream(sph_handle *h, void *hip_stream) {
     if (!h) return SPH_EINVAL;
     HIPCHK(h, hipStreamSynchronize(h->compute));
     if (!h->ownCompute) h->ownCompute = h->compute;
-    h->compute = hip_stream ? (hipStream_t)hip_stream : h->ownCompute;
+    // NULL is HIP's default ("null") stream -- what torch.cuda.current_stream()
+    // reports unless the caller switched streams.
+    h->compute = (hipStream_t)hip_stream;
     return SPH_OK;
 }
 

@@ -158,7 +158,7 @@ int sph_sort_check(int device, const uint32_t *keys, int n, int key_bits,
  * particles each -- and exchanges halo / migrant ranges of them with RCCL
  * send/recv; the library only runs kernels on ranges of those buffers, on the
  * caller's stream (so it is stream-ordered with the collectives). */
-int sph_set_stream(sph_handle *h, void *hip_stream); /* NULL = handle's own stream */
+int sph_set_stream(sph_handle *h, void *hip_stream); /* a hipStream_t; NULL = HIP's default stream */
 int sph_bind_buffers(sph_handle *h, void *pos4_a, void *vel4_a, void *pos4_b,
                      void *vel4_b, int capacity);
 /* Hash + stable radix sort + gather of particles [src_offset, src_offset+count)
