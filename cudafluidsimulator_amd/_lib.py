@@ -52,7 +52,8 @@ class SphKernelTimes(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # SPH_LIB_PATH: A/B experiments with differently-built libraries (same ABI)
+    return os.environ.get("SPH_LIB_PATH") or os.path.join(_HERE, _LIB_NAME)
 
 
 _lib = None

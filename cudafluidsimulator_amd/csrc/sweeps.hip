@@ -224,14 +224,21 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_direct(DevParams P, SweepA
 }
 
 // =====================  LDS variant (production)  ============================
-// Walks the nine runs of the lanes of one wave.  `V.candidate(j, pj, active)` is
-// called once per loop trip for every lane (active = this lane really has a
-// candidate); `V.poll()` is called wave-uniformly after each trip.
+// Walks the nine runs of the lanes of one wave.  The inner loop is branch-free
+// and unrolled by SW_UNROLL: each trip issues SW_UNROLL ds_read_b128 up front and
+// calls V.candidate(j, pj) for every lane; a lane that has run out of candidates
+// reads the SENTINEL slot (a point 1e18 away: it fails every radius test), so no
+// per-lane exec masking is needed.  V.poll() is called wave-uniformly once per
+// trip.
+#define SW_UNROLL 4
+#define SW_SENTINEL SW_CAP // index of the far-away point inside the stage slice
+
 template <class Visitor>
 __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict__ stage,
                                           int lane, bool valid, int rowId,
                                           const int (&js)[9], const int (&je)[9],
                                           Visitor &V) {
+    if (lane < SW_UNROLL) stage[SW_SENTINEL + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
     unsigned long long todo = __ballot(valid);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -253,14 +260,29 @@ __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict
                 for (int k = lane; k < len; k += SPH_WAVE) stage[k] = A.pos4[cs + k];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                int a = nonempty ? max(js[r], cs) : 0;
-                const int b = nonempty ? min(je[r], cs + len) : 0;
-                while (__ballot(a < b)) {
-                    const bool on = a < b;
-                    float4 pj = stage[on ? (a - cs) : 0];
-                    V.candidate(a, pj, on);
+                const int a = nonempty ? max(js[r], cs) - cs : 0;      // first local slot
+                const int b = nonempty ? min(je[r], cs + len) - cs : 0; // one past last
+                // per-lane cursor: LDS slot, candidates left, global index
+                const float4 *cur = stage + a;
+                const float4 *const sent = stage + SW_SENTINEL;
+                int rem = max(b - a, 0);
+                int jcur = cs + a;
+                for (; __ballot(rem > 0); rem -= SW_UNROLL, cur += SW_UNROLL, jcur += SW_UNROLL) {
+                    float4 pj[SW_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) {
+                        // exhausted lanes read sentinel slot u (the +u folds into the
+                        // ds_read offset field either way)
+                        const float4 *p = (rem > u) ? cur : sent;
+                        pj[u] = p[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) V.candidate(jcur + u, pj[u]);
+                    // keep .w live so each read is one ds_read_b128 (4 LDS cycles per
+                    // wave) instead of the ds_read_b96 (8 cycles) hipcc would pick
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
                     V.poll();
-                    ++a;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -273,14 +295,22 @@ struct DensityVisitor {
     const DevParams &P;
     float pix, piy, piz;
     float rho;
-    __device__ __forceinline__ void candidate(int, float4 pj, bool on) {
-        if (on) density_pair(P, pix, piy, piz, pj, rho);
+    // densityKernel (simulator.cu:84-97) + `density += MASS * W` (:179), branch-free:
+    // diff = max(h2 - dist2, 0) makes W exactly +0 outside the radius, and adding
+    // +0 never changes rho (rho >= +0), so this equals the reference's early return.
+    __device__ __forceinline__ void candidate(int, float4 pj) {
+        float dx = pix - pj.x;
+        float dy = piy - pj.y;
+        float dz = piz - pj.z;
+        float dist2 = dx * dx + dy * dy + dz * dz;
+        float diff = fmaxf(P.h2 - dist2, 0.f);
+        rho += SPH_MASS * (P.dcoef * diff * diff * diff);
     }
     __device__ __forceinline__ void poll() {}
 };
 
 __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepArgs A) {
-    __shared__ float4 stageAll[SW_WAVES][SW_CAP];
+    __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,57 +334,84 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
     }
 }
 
+#ifndef SW_DRAIN
+#define SW_DRAIN 4 // FIFO entries evaluated per drain (loads of all issued first)
+#endif
+#ifndef SW_PUSH_BRANCHFREE
+#define SW_PUSH_BRANCHFREE 0
+#endif
+
 struct ForceVisitor {
     const DevParams &P;
     const SweepArgs &A;
     uint32_t *queue; // this wave's FIFO storage: [SW_QCAP][64]
     int lane;
+    uint32_t selfIdx; // a candidate that contributes exactly nothing (dist = 0)
     float pix, piy, piz, vix, viy, viz, prs_i;
     uint32_t head, tail;
     ForceAcc F;
 
-    __device__ __forceinline__ void candidate(int j, float4 pj, bool on) {
+    __device__ __forceinline__ void candidate(int j, float4 pj) {
         float dx = pix - pj.x;
         float dy = piy - pj.y;
         float dz = piz - pj.z;
         float dist2 = dx * dx + dy * dy + dz * dz;
-        if (on && !(dist2 > P.cut2)) {
+#if SW_PUSH_BRANCHFREE
+        // the slot at `tail` is always free here (poll() keeps SW_UNROLL slots
+        // spare), so store unconditionally and only advance on a hit
+        queue[(tail & (SW_QCAP - 1)) * SPH_WAVE + lane] = (uint32_t)j;
+        tail += !(dist2 > P.cut2) ? 1u : 0u;
+#else
+        if (!(dist2 > P.cut2)) {
             queue[(tail & (SW_QCAP - 1)) * SPH_WAVE + lane] = (uint32_t)j;
             ++tail;
         }
+#endif
     }
-    // pop one hit per lane and evaluate it
-    __device__ __forceinline__ void drain_one() {
-        const bool has = tail != head;
-        uint32_t j = queue[(head & (SW_QCAP - 1)) * SPH_WAVE + lane];
-        if (has) {
-            ++head;
-            float4 pj = A.pos4[j];
-            float4 vj = A.vel4[j];
-            force_pair(P, pix, piy, piz, vix, viy, viz, prs_i, pj, vj, F);
+    // Pop up to SW_DRAIN hits per lane, issue all their loads, then evaluate them
+    // in FIFO order.  An empty slot is replaced by the particle itself, whose
+    // pair terms are gated off by dist < EPS_F -- an exact no-op.
+    __device__ __forceinline__ void drain() {
+        const uint32_t have = tail - head;
+        uint32_t j[SW_DRAIN];
+        float4 pj[SW_DRAIN], vj[SW_DRAIN];
+#pragma unroll
+        for (int u = 0; u < SW_DRAIN; ++u) {
+            uint32_t q = queue[((head + u) & (SW_QCAP - 1)) * SPH_WAVE + lane];
+            j[u] = ((uint32_t)u < have) ? q : selfIdx;
         }
+#pragma unroll
+        for (int u = 0; u < SW_DRAIN; ++u) {
+            pj[u] = A.pos4[j[u]];
+            vj[u] = A.vel4[j[u]];
+        }
+        head += min(have, (uint32_t)SW_DRAIN);
+#pragma unroll
+        for (int u = 0; u < SW_DRAIN; ++u)
+            force_pair(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
     }
     __device__ __forceinline__ void poll() {
-        // a full FIFO anywhere in the wave forces one body iteration
-        while (__ballot((tail - head) >= SW_QCAP)) drain_one();
+        // the next trip pushes at most SW_UNROLL entries per lane
+        while (__ballot((tail - head) > (uint32_t)(SW_QCAP - SW_UNROLL))) drain();
     }
     __device__ __forceinline__ void flush() {
-        while (__ballot(tail != head)) drain_one();
+        while (__ballot(tail != head)) drain();
     }
 };
 
 __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs A) {
-    __shared__ float4 stageAll[SW_WAVES][SW_CAP];
+    __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     __shared__ uint32_t queueAll[SW_WAVES][SW_QCAP * SPH_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
-    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
-    float4 vi = valid ? A.vel4[i] : make_float4(0, 0, 0, 1.f);
+    const int iSafe = valid ? i : A.i_begin; // i_end > i_begin whenever we are launched
+    float4 pi = A.pos4[iSafe];
+    float4 vi = A.vel4[iSafe];
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
     int js[9], je[9];
     load_runs(P, A.cellRange, c, valid, js, je);
-    ForceVisitor V{P, A, queueAll[w], lane, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
+    ForceVisitor V{P, A, queueAll[w], lane, (uint32_t)iSafe, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
                    fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY)),
                    0u, 0u, {0.f, 0.f, 0.f}};
     wave_walk(A, stageAll[w], lane, valid, c.y + c.z * P.D, js, je, V);
