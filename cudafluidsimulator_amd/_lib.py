@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sph_get_kernel_times", "sph_last_error", "sph_phase_grid", "sph_phase_density",
     "sph_phase_force", "sph_phase_readback", "sph_sort_check", "sph_build_info",
     "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_density",
-    "sph_slab_force", "sph_initial_positions",
+    "sph_slab_force", "sph_initial_positions", "sph_save_state", "sph_load_state",
 ]
 
 
@@ -89,6 +89,8 @@ def load_library():
     L.sph_download_force.argtypes = [hp, fp]
     L.sph_download_grid.argtypes = [hp, u32p, u32p, i32p]
     L.sph_sync.argtypes = [hp]
+    L.sph_save_state.argtypes = [hp, C.c_char_p]
+    L.sph_load_state.argtypes = [hp, C.c_char_p]
     L.sph_num_particles.argtypes = [hp]
     L.sph_get_kernel_times.argtypes = [hp, C.POINTER(SphKernelTimes), C.c_int]
     L.sph_last_error.argtypes = [hp]

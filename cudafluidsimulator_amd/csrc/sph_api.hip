@@ -729,6 +729,83 @@ const float *sph_positions_host(sph_handle *h) {
     return h->hostPos;
 }
 
+namespace {
+struct SnapshotHeader { // 64 bytes
+    char magic[8];      // "SPHSNAP1"
+    int32_t n;
+    int32_t reserved;
+    int64_t stepIndex;
+    SphSettings settings; // 32 bytes
+    char pad[8];
+};
+static_assert(sizeof(SnapshotHeader) == 64, "snapshot header");
+} // namespace
+
+int sph_save_state(sph_handle *h, const char *path) {
+    if (!h || !path) return SPH_EINVAL;
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
+    if (!h->ready || h->phase != 0) return fail(h, SPH_ESTATE, "no complete state to save");
+    int rc = sph_sync(h);
+    if (rc) return rc;
+    const size_t n = (size_t)h->n;
+    std::vector<float4> p4(n ? n : 1), v4(n ? n : 1);
+    if (n) {
+        HIPCHK(h, hipMemcpy(p4.data(), h->pos4[h->cur], n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(v4.data(), h->vel4[h->cur], n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    SnapshotHeader hd{};
+    memcpy(hd.magic, "SPHSNAP1", 8);
+    hd.n = h->n;
+    hd.stepIndex = h->stepIndex;
+    hd.settings = h->settings;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(h, SPH_EINVAL, std::string("cannot open ") + path);
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && (n == 0 || (fwrite(p4.data(), sizeof(float4), n, f) == n &&
+                                                                fwrite(v4.data(), sizeof(float4), n, f) == n));
+    ok = (fclose(f) == 0) && ok;
+    return ok ? SPH_OK : fail(h, SPH_EINVAL, "short write");
+}
+
+int sph_load_state(sph_handle *h, const char *path) {
+    if (!h || !path) return SPH_EINVAL;
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(h, SPH_EINVAL, std::string("cannot open ") + path);
+    SnapshotHeader hd{};
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "SPHSNAP1", 8) == 0;
+    if (ok && (hd.n != h->n || memcmp(&hd.settings.h, &h->settings.h, 24) != 0)) {
+        fclose(f);
+        return fail(h, SPH_EINVAL, "snapshot does not match this simulator's settings");
+    }
+    const size_t n = (size_t)h->n;
+    std::vector<float4> p4(n ? n : 1), v4(n ? n : 1);
+    ok = ok && (n == 0 || (fread(p4.data(), sizeof(float4), n, f) == n && fread(v4.data(), sizeof(float4), n, f) == n));
+    fclose(f);
+    if (!ok) return fail(h, SPH_EINVAL, "not a snapshot / truncated");
+    std::vector<char> seen(n ? n : 1, 0);
+    for (size_t i = 0; i < n; ++i) { // ids must be a permutation: they index devicePosition
+        uint32_t id;
+        memcpy(&id, &p4[i].w, 4);
+        if (id >= n || seen[id]) return fail(h, SPH_EINVAL, "corrupt snapshot (ids)");
+        seen[id] = 1;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->compute));
+    HIPCHK(h, hipStreamSynchronize(h->copy));
+    h->cur = 0;
+    if (n) {
+        HIPCHK(h, hipMemcpy(h->pos4[0], p4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->vel4[0], v4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    h->ready = true;
+    h->gridValid = false;
+    h->phase = 0;
+    h->sorted = -1;
+    h->stepIndex = hd.stepIndex;
+    h->copyPending[0] = h->copyPending[1] = false;
+    return SPH_OK;
+}
+
 int sph_sync(sph_handle *h) {
     if (!h) return SPH_EINVAL;
     HIPCHK(h, hipStreamSynchronize(h->compute));

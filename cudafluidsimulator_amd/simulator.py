@@ -146,6 +146,12 @@ class Simulator:
             cells.ctypes.data_as(C.POINTER(C.c_int32))), "sph_download_grid")
         return dict(ids=ids, keys=keys, cells=cells)
 
+    def save_state(self, path):
+        self._check(self._L.sph_save_state(self._h, str(path).encode()), "sph_save_state")
+
+    def load_state(self, path):
+        self._check(self._L.sph_load_state(self._h, str(path).encode()), "sph_load_state")
+
     def phase(self, name):
         self._check(getattr(self._L, "sph_phase_" + name)(self._h), "sph_phase_" + name)
 

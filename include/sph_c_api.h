@@ -136,6 +136,13 @@ int sph_download_force(sph_handle *h, float *force_xyz); /* SPH_FLAG_STORE_FORCE
 int sph_download_grid(sph_handle *h, uint32_t *ids, uint32_t *keys,
                       int32_t *cell_ranges);
 
+/* Checkpoint / resume (no reference counterpart).  The file
+ * is a raw snapshot of the two cell-sorted float4 streams (ids included) plus a
+ * 64-byte header, so a resumed run continues BIT-IDENTICALLY (the canonical
+ * summation order depends on the stored order, not only on positions). */
+int sph_save_state(sph_handle *h, const char *path);
+int sph_load_state(sph_handle *h, const char *path);
+
 int sph_sync(sph_handle *h);
 int sph_num_particles(const sph_handle *h);
 int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset);

@@ -186,6 +186,29 @@ def test_click_impulse_matches_oracle():
     sim.close()
 
 
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    pos, vel = clustered_state(20000, 17)
+    a, ref = make_pair(len(pos), False, pos=pos, vel=vel)
+    for _ in range(4):
+        a.simulate()
+    snap = tmp_path / "state.sphsnap"
+    a.save_state(snap)
+    for _ in range(4):
+        a.simulate()
+    b = sph.Simulator(sph.default_settings(len(pos), False))
+    b.load_state(snap)
+    for _ in range(4):
+        b.simulate()
+    sa, sb = a.download_state(), b.download_state()
+    for k in sa:
+        assert_bit_equal(sa[k], sb[k], "resume:" + k)
+    ref.step(8)
+    assert_bit_equal(sb["pos"], ref.download()["pos"], "resume vs oracle")
+    with pytest.raises(sph.SphError, match="match"):
+        sph.Simulator(sph.default_settings(10, False)).load_state(snap)
+    a.close(); b.close()
+
+
 def test_api_errors():
     s = sph.default_settings(10, False)
     sim = sph.Simulator(s)
