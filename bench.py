@@ -114,6 +114,8 @@ def main():
         elapsed = time.perf_counter() - t0
         kt = sim.kernel_times()
         result = dict(elapsed=elapsed, kt=kt, times=times, n_total=n)
+        if os.environ.get("SPH_STAMPS"):
+            result["stamps"] = sim.debug_counters()
         sim.close()
 
     if world > 1:
@@ -166,6 +168,8 @@ def main():
             t = result["times"]
             out["m_time_table_s"] = {"grid_construction": t.buildGrid, "sph_update": t.sphUpdate,
                                      "data_transfer_exposed": t.memcpy}
+        if "stamps" in result:
+            out["debug_stamps"] = result["stamps"]
         if args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_particles or n, random_init, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "sph_phase_force", "sph_phase_readback", "sph_sort_check", "sph_build_info",
     "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_density",
     "sph_slab_force", "sph_initial_positions", "sph_save_state", "sph_load_state",
+    "sph_debug_counters",
 ]
 
 
@@ -89,6 +90,7 @@ def load_library():
     L.sph_download_force.argtypes = [hp, fp]
     L.sph_download_grid.argtypes = [hp, u32p, u32p, i32p]
     L.sph_sync.argtypes = [hp]
+    L.sph_debug_counters.argtypes = [hp, C.POINTER(C.c_uint64)]
     L.sph_save_state.argtypes = [hp, C.c_char_p]
     L.sph_load_state.argtypes = [hp, C.c_char_p]
     L.sph_num_particles.argtypes = [hp]

@@ -217,9 +217,9 @@ int alloc_device(sph_handle *h) {
     }
     if (h->opt.flags & SPH_FLAG_STORE_FORCE)
         HIPCHK(h, hipMalloc(&h->force4, cap * sizeof(float4)));
-    HIPCHK(h, hipMalloc(&h->pairCounter, sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(h->pairCounter, 0, sizeof(unsigned long long)));
-    HIPCHK(h, hipHostMalloc(&h->pairHost, sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(h, hipMalloc(&h->pairCounter, 16 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->pairCounter, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(h, hipHostMalloc(&h->pairHost, 16 * sizeof(unsigned long long), hipHostMallocDefault));
     *h->pairHost = 0;
     for (auto &se : h->ring) {
         for (auto &e : se.e) HIPCHK(h, hipEventCreate(&e));
@@ -895,8 +895,17 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     *out = h->kt;
     if (reset) {
         h->kt = SphKernelTimes{};
-        HIPCHK(h, hipMemset(h->pairCounter, 0, sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->pairCounter, 0, 16 * sizeof(unsigned long long)));
     }
+    return SPH_OK;
+}
+
+int sph_debug_counters(sph_handle *h, uint64_t *out16) {
+    if (!h || !out16) return SPH_EINVAL;
+    int rc = sph_sync(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; ++k) out16[k] = h->pairHost[k];
     return SPH_OK;
 }
 

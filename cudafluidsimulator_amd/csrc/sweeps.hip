@@ -53,22 +53,29 @@ __device__ __forceinline__ void load_runs(const DevParams &P,
                                           int (&je)[9]) {
     const int x0 = max(c.x - 1, 0), x1 = min(c.x + 1, P.D - 1);
     const int xm = min(x0 + 1, x1);
+    // All 27 table reads are issued before any is used (rows outside the grid are
+    // clamped for the load and discarded afterwards): one L2 round trip per
+    // particle instead of nine dependent ones.
+    int2 r0[9], r1[9], r2[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int sz = min(max(c.z + (r / 3 - 1), 0), P.D - 1);
+        const int sy = min(max(c.y + (r % 3 - 1), 0), P.D - 1);
+        const int base = sy * P.D + sz * P.D * P.D;
+        r0[r] = cellRange[base + x0];
+        r1[r] = cellRange[base + xm];
+        r2[r] = cellRange[base + x1];
+    }
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         const int sz = c.z + (r / 3 - 1), sy = c.y + (r % 3 - 1);
-        js[r] = 0;
-        je[r] = 0;
-        if (valid && sy >= 0 && sy < P.D && sz >= 0 && sz < P.D) {
-            const int base = sy * P.D + sz * P.D * P.D;
-            int2 r0 = cellRange[base + x0];
-            int2 r1 = cellRange[base + xm];
-            int2 r2 = cellRange[base + x1];
-            bool n0 = r0.y > r0.x, n1 = r1.y > r1.x, n2 = r2.y > r2.x;
-            if (n0 | n1 | n2) {
-                js[r] = n0 ? r0.x : (n1 ? r1.x : r2.x);
-                je[r] = n2 ? r2.y : (n1 ? r1.y : r0.y);
-            }
-        }
+        const bool inGrid = valid && sy >= 0 && sy < P.D && sz >= 0 && sz < P.D;
+        const bool n0 = r0[r].y > r0[r].x, n1 = r1[r].y > r1[r].x, n2 = r2[r].y > r2[r].x;
+        const bool any = inGrid && (n0 | n1 | n2);
+        const int s = n0 ? r0[r].x : (n1 ? r1[r].x : r2[r].x);
+        const int e = n2 ? r2[r].y : (n1 ? r1[r].y : r0[r].y);
+        js[r] = any ? s : 0;
+        je[r] = any ? e : 0;
     }
 }
 
@@ -241,14 +248,40 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_direct(DevParams P, SweepA
 // reads the SENTINEL slot (a point 1e18 away: it fails every radius test), so no
 // per-lane exec masking is needed.  V.poll() is called wave-uniformly once per
 // trip.
+// In-kernel phase stamps (diagnostic builds only: -DSW_STAMPS=1).  Sums of
+// s_memtime deltas per phase go to counters 1.. of A.pairCounter; the shipped
+// build executes none of this.
+#ifndef SW_STAMPS
+#define SW_STAMPS 0
+#endif
+#if SW_STAMPS
+__device__ __forceinline__ unsigned long long sw_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define SW_STAMP(var) unsigned long long var = sw_stamp()
+#else
+#define SW_STAMP(var)
+#endif
+struct WalkStamps {
+    unsigned long long stage = 0, test = 0;
+};
+
 #define SW_UNROLL 4
+#ifndef SW_PIPELINE
+#define SW_PIPELINE 1
+#endif
 #define SW_SENTINEL SW_CAP // index of the far-away point inside the stage slice
 
 template <class Visitor>
 __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict__ stage,
                                           int lane, bool valid, int rowId,
                                           const int (&js)[9], const int (&je)[9],
-                                          Visitor &V) {
+                                          Visitor &V, WalkStamps &W) {
+    (void)W;
     if (lane < SW_UNROLL) stage[SW_SENTINEL + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
     unsigned long long todo = __ballot(valid);
     while (todo) {
@@ -276,10 +309,15 @@ __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict
             const int u0 = __builtin_amdgcn_readlane(jsr, lo);
             const int u1 = __builtin_amdgcn_readlane(jer, hi);
             for (int cs = u0; cs < u1; cs += SW_CAP) {
+                SW_STAMP(tA);
                 const int len = min(SW_CAP, u1 - cs);
                 for (int k = lane; k < len; k += SPH_WAVE) stage[k] = A.pos4[cs + k];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+#if SW_STAMPS
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                SW_STAMP(tB);
                 const int a = nonempty ? max(jsr, cs) - cs : 0;      // first local slot
                 const int b = nonempty ? min(jer, cs + len) - cs : 0; // one past last
                 // per-lane cursor: LDS slot, candidates left, global index
@@ -287,6 +325,37 @@ __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict
                 const float4 *const sent = stage + SW_SENTINEL;
                 int rem = max(b - a, 0);
                 int jcur = cs + a;
+#if SW_PIPELINE
+                // Software-pipelined by one trip: the ds_read_b128 of trip t+1 are
+                // in flight while trip t is evaluated, so the wave does not park on
+                // LDS latency once per trip (two register sets, A and B).
+                float4 pa[SW_UNROLL], pb[SW_UNROLL];
+#define SW_ISSUE(dst, remv, curv)                                              \
+    _Pragma("unroll") for (int u = 0; u < SW_UNROLL; ++u) {                    \
+        const float4 *p_ = ((remv) > u) ? (curv) : sent;                       \
+        dst[u] = p_[u];                                                        \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0); /* keep the reads ahead of the math */
+#define SW_CONSUME(src)                                                        \
+    _Pragma("unroll") for (int u = 0; u < SW_UNROLL; ++u)                      \
+        V.candidate(jcur + u, src[u]);                                         \
+    _Pragma("unroll") for (int u = 0; u < SW_UNROLL; ++u)                      \
+        asm volatile("" ::"v"(src[u].w));                                      \
+    V.poll();                                                                  \
+    rem -= SW_UNROLL;                                                          \
+    cur += SW_UNROLL;                                                          \
+    jcur += SW_UNROLL;
+                SW_ISSUE(pa, rem, cur)
+                while (__ballot(rem > 0)) {
+                    SW_ISSUE(pb, rem - SW_UNROLL, cur + SW_UNROLL)
+                    SW_CONSUME(pa)
+                    if (!__ballot(rem > 0)) break;
+                    SW_ISSUE(pa, rem - SW_UNROLL, cur + SW_UNROLL)
+                    SW_CONSUME(pb)
+                }
+#undef SW_ISSUE
+#undef SW_CONSUME
+#else
                 for (; __ballot(rem > 0); rem -= SW_UNROLL, cur += SW_UNROLL, jcur += SW_UNROLL) {
                     float4 pj[SW_UNROLL];
 #pragma unroll
@@ -304,8 +373,14 @@ __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict
                     for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
                     V.poll();
                 }
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+#if SW_STAMPS
+                SW_STAMP(tC);
+                W.stage += tB - tA;
+                W.test += tC - tB;
+#endif
             }
         }
     }
@@ -333,6 +408,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
+    SW_STAMP(t0);
     const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
@@ -347,11 +423,27 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
         if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
     }
     DensityVisitor V{P, pi.x, pi.y, pi.z, 0.f};
-    wave_walk(A, stage, lane, valid, c.y + c.z * P.D, js, je, V);
+    WalkStamps W;
+#if SW_STAMPS
+    asm volatile("" ::"v"(js[0] + je[8]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    SW_STAMP(t1);
+    wave_walk(A, stage, lane, valid, c.y + c.z * P.D, js, je, V, W);
     if (valid) {
         float rho = fmaxf(V.rho, SPH_EPS_F);
         A.vel4[i].w = rho;
     }
+#if SW_STAMPS
+    SW_STAMP(t2);
+    if (lane == 0 && A.pairCounter) {
+        atomicAdd(A.pairCounter + 1, t1 - t0);  // prologue
+        atomicAdd(A.pairCounter + 2, W.stage);  // staging (global -> LDS) incl. waits
+        atomicAdd(A.pairCounter + 3, W.test);   // test loops
+        atomicAdd(A.pairCounter + 4, t2 - t0);  // whole wave
+        atomicAdd(A.pairCounter + 5, 1ull);     // waves
+    }
+#endif
 }
 
 #ifndef SW_DRAIN
@@ -370,6 +462,7 @@ struct ForceVisitor {
     float pix, piy, piz, vix, viy, viz, prs_i;
     uint32_t head, tail;
     ForceAcc F;
+    unsigned long long drains = 0;
 
     __device__ __forceinline__ void candidate(int j, float4 pj) {
         float dx = pix - pj.x;
@@ -392,6 +485,9 @@ struct ForceVisitor {
     // in FIFO order.  An empty slot is replaced by the particle itself, whose
     // pair terms are gated off by dist < EPS_F -- an exact no-op.
     __device__ __forceinline__ void drain() {
+#if SW_STAMPS
+        ++drains;
+#endif
         const uint32_t have = tail - head;
         uint32_t j[SW_DRAIN];
         float4 pj[SW_DRAIN], vj[SW_DRAIN];
@@ -423,6 +519,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     __shared__ uint32_t queueAll[SW_WAVES][SW_QCAP * SPH_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    SW_STAMP(t0);
     const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     const int iSafe = valid ? i : A.i_begin; // i_end > i_begin whenever we are launched
@@ -434,13 +531,32 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
     ForceVisitor V{P, A, queueAll[w], lane, (uint32_t)iSafe, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
                    fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY)),
                    0u, 0u, {0.f, 0.f, 0.f}};
-    wave_walk(A, stageAll[w], lane, valid, c.y + c.z * P.D, js, je, V);
+    WalkStamps W;
+#if SW_STAMPS
+    asm volatile("" ::"v"(js[0] + je[8]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    SW_STAMP(t1);
+    wave_walk(A, stageAll[w], lane, valid, c.y + c.z * P.D, js, je, V, W);
+    SW_STAMP(t2);
     V.flush();
+    SW_STAMP(t3);
     if (valid) {
         float vx = vi.x, vy = vi.y, vz = vi.z;
         integrate_particle(P, pi, vx, vy, vz, V.F, vi.w);
         store_particle(A, i, pi, vx, vy, vz, vi.w, V.F);
     }
+#if SW_STAMPS
+    SW_STAMP(t4);
+    if (lane == 0 && A.pairCounter) {
+        atomicAdd(A.pairCounter + 6, t1 - t0);   // prologue
+        atomicAdd(A.pairCounter + 7, W.stage);   // staging
+        atomicAdd(A.pairCounter + 8, W.test);    // test loops incl. drains they trigger
+        atomicAdd(A.pairCounter + 9, t3 - t2);   // final flush
+        atomicAdd(A.pairCounter + 10, t4 - t0);  // whole wave
+        atomicAdd(A.pairCounter + 11, V.drains); // drain() calls
+    }
+#endif
 }
 
 void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode, int sweep,

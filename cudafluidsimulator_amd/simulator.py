@@ -146,6 +146,11 @@ class Simulator:
             cells.ctypes.data_as(C.POINTER(C.c_int32))), "sph_download_grid")
         return dict(ids=ids, keys=keys, cells=cells)
 
+    def debug_counters(self):
+        out = (C.c_uint64 * 16)()
+        self._check(self._L.sph_debug_counters(self._h, out), "sph_debug_counters")
+        return list(out)
+
     def save_state(self, path):
         self._check(self._L.sph_save_state(self._h, str(path).encode()), "sph_save_state")
 

@@ -147,6 +147,9 @@ int sph_sync(sph_handle *h);
 int sph_num_particles(const sph_handle *h);
 int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset);
 const char *sph_last_error(const sph_handle *h); /* h may be NULL: create errors */
+/* Diagnostics: [0] = pair tests; [1..] = in-kernel phase stamps, filled only by a
+ * -DSW_STAMPS=1 build of the library (see sweeps.hip), zero otherwise. */
+int sph_debug_counters(sph_handle *h, uint64_t *out16);
 
 /* ---- the step split into its phases (tests, profiling, slab driver) ---- */
 int sph_phase_grid(sph_handle *h);     /* kernelBuildGrid + kernelResetGrid */
