@@ -28,6 +28,7 @@ namespace {
 thread_local std::string g_create_error;
 
 constexpr int kEventRing = 64;
+constexpr int kCounterWords = 16 + 256 * 16; // [0] pair tests, then 256 shards of stamps
 
 struct PairEvent { // one timed section of the slab path
     hipEvent_t a = nullptr, b = nullptr;
@@ -217,9 +218,9 @@ int alloc_device(sph_handle *h) {
     }
     if (h->opt.flags & SPH_FLAG_STORE_FORCE)
         HIPCHK(h, hipMalloc(&h->force4, cap * sizeof(float4)));
-    HIPCHK(h, hipMalloc(&h->pairCounter, 16 * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(h->pairCounter, 0, 16 * sizeof(unsigned long long)));
-    HIPCHK(h, hipHostMalloc(&h->pairHost, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(h, hipMalloc(&h->pairCounter, kCounterWords * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->pairCounter, 0, kCounterWords * sizeof(unsigned long long)));
+    HIPCHK(h, hipHostMalloc(&h->pairHost, kCounterWords * sizeof(unsigned long long), hipHostMallocDefault));
     *h->pairHost = 0;
     for (auto &se : h->ring) {
         for (auto &e : se.e) HIPCHK(h, hipEventCreate(&e));
@@ -302,6 +303,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.host_order_pos = nullptr;
     A.force_out = h->force4;
     A.pairCounter = nullptr;
+    A.stampCounter = (h->opt.flags & SPH_FLAG_COUNT_PAIRS) ? h->pairCounter : nullptr;
     A.i_begin = 0;
     A.i_end = h->n;
     A.n_all = h->n;
@@ -895,7 +897,7 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     *out = h->kt;
     if (reset) {
         h->kt = SphKernelTimes{};
-        HIPCHK(h, hipMemset(h->pairCounter, 0, 16 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->pairCounter, 0, kCounterWords * sizeof(unsigned long long)));
     }
     return SPH_OK;
 }
@@ -904,8 +906,10 @@ int sph_debug_counters(sph_handle *h, uint64_t *out16) {
     if (!h || !out16) return SPH_EINVAL;
     int rc = sph_sync(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; ++k) out16[k] = h->pairHost[k];
+    for (int sh = 0; sh < 256; ++sh)
+        for (int k = 1; k < 16; ++k) out16[k] += h->pairHost[16 + sh * 16 + k];
     return SPH_OK;
 }
 

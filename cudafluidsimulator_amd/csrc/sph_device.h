@@ -82,6 +82,7 @@ struct SweepArgs {
     float *host_order_pos;    // n x 3 floats by original id (may be null)
     float4 *force_out;        // optional (SPH_FLAG_STORE_FORCE)
     unsigned long long *pairCounter; // optional (SPH_FLAG_COUNT_PAIRS)
+    unsigned long long *stampCounter; // diagnostic builds only (same buffer)
     int i_begin, i_end;       // owned range (whole array for one domain)
     int n_all;
 };

@@ -274,6 +274,13 @@ struct WalkStamps {
 #ifndef SW_PIPELINE
 #define SW_PIPELINE 1
 #endif
+// Negative results kept out of the code (measured on MI355X, n = 4,194,304):
+//  * streaming the next run with global_load_lds (LDS-DMA) while the current one
+//    is tested: density 1.29 ms vs 0.98 ms -- hipcc drains lgkmcnt(0) on every LDS
+//    read while a global_load_lds is outstanding;
+//  * staging three runs per round trip (3 sub-buffers): staging stamps fell from
+//    32k to 20k cycles per wave but the extra registers cost a wave per SIMD and
+//    the sweeps got slower (density 1.02 ms, force 2.62 ms vs 0.98 / 2.40).
 #define SW_SENTINEL SW_CAP // index of the far-away point inside the stage slice
 
 template <class Visitor>
@@ -436,12 +443,13 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
     }
 #if SW_STAMPS
     SW_STAMP(t2);
-    if (lane == 0 && A.pairCounter) {
-        atomicAdd(A.pairCounter + 1, t1 - t0);  // prologue
-        atomicAdd(A.pairCounter + 2, W.stage);  // staging (global -> LDS) incl. waits
-        atomicAdd(A.pairCounter + 3, W.test);   // test loops
-        atomicAdd(A.pairCounter + 4, t2 - t0);  // whole wave
-        atomicAdd(A.pairCounter + 5, 1ull);     // waves
+    if (lane == 0 && A.pairCounter) { // 256 shards: same-address atomics would distort
+        unsigned long long *S = A.pairCounter + 16 + (blockIdx.x & 255) * 16;
+        atomicAdd(S + 1, t1 - t0);  // prologue
+        atomicAdd(S + 2, W.stage);  // staging (global -> LDS) incl. waits
+        atomicAdd(S + 3, W.test);   // test loops
+        atomicAdd(S + 4, t2 - t0);  // whole wave
+        atomicAdd(S + 5, 1ull);     // waves
     }
 #endif
 }
@@ -548,13 +556,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
     }
 #if SW_STAMPS
     SW_STAMP(t4);
-    if (lane == 0 && A.pairCounter) {
-        atomicAdd(A.pairCounter + 6, t1 - t0);   // prologue
-        atomicAdd(A.pairCounter + 7, W.stage);   // staging
-        atomicAdd(A.pairCounter + 8, W.test);    // test loops incl. drains they trigger
-        atomicAdd(A.pairCounter + 9, t3 - t2);   // final flush
-        atomicAdd(A.pairCounter + 10, t4 - t0);  // whole wave
-        atomicAdd(A.pairCounter + 11, V.drains); // drain() calls
+    if (lane == 0 && A.stampCounter) {
+        unsigned long long *S = A.stampCounter + 16 + (blockIdx.x & 255) * 16;
+        atomicAdd(S + 6, t1 - t0);   // prologue
+        atomicAdd(S + 7, W.stage);   // staging
+        atomicAdd(S + 8, W.test);    // test loops incl. drains they trigger
+        atomicAdd(S + 9, t3 - t2);   // final flush
+        atomicAdd(S + 10, t4 - t0);  // whole wave
+        atomicAdd(S + 11, V.drains); // drain() calls
     }
 #endif
 }
