@@ -37,6 +37,9 @@ def parse():
                     help="BASELINE.json configs[2]: -n 4194304 -i random -m time")
     ap.add_argument("--init", choices=["random", "grid"], default="random")
     ap.add_argument("--sweep", choices=["lds", "direct"], default="lds")
+    ap.add_argument("--math", choices=["strict", "fast"], default="strict",
+                    help="strict: bit-identical to the oracle (default); fast: FMA + approximate "
+                         "rcp/rsq, tolerance-checked")
     ap.add_argument("--mode", choices=["time", "free"], default="time",
                     help="time: simulateAndTime loop (-m time); free: simulate() loop")
     ap.add_argument("--cpu-steps", type=int, default=4,
@@ -92,7 +95,8 @@ def main():
         result = run_slab_bench(args, dist, rank, world, local_rank)
     else:
         s = sph.default_settings(n, random_init)
-        sim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank)
+        sim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank,
+                            math=args.math)
         sim.setup()
         times = sph.Times()
         for _ in range(W):
@@ -155,7 +159,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"-n {result['n_total']} -i {args.init} -m {args.mode}, "
                                    f"{world}xMI355X, flattened-index radix sort + float4 SoA, "
-                                   f"strict fp32 (bit-identical to the CPU oracle)",
+                                   + ("strict fp32 (bit-identical to the CPU oracle)" if args.math == "strict"
+                                      else "FAST fp32 math (FMA, approximate rcp/rsq; 1e-5 tolerance mode)"),
                        "sweep": args.sweep,
                        "parallelism": "single domain" if world == 1 else f"z-slabs x{world} + RCCL halo"},
             "roofline": roof,

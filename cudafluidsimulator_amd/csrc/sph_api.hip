@@ -513,9 +513,13 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
         h->opt.device = -1;
     }
     h->opt.struct_size = (int32_t)sizeof(SphOptions);
-    if (h->opt.math_mode != SPH_MATH_STRICT) {
+    if (h->opt.math_mode != SPH_MATH_STRICT && h->opt.math_mode != SPH_MATH_FAST) {
         delete h;
-        return fail(nullptr, SPH_EINVAL, "only SPH_MATH_STRICT is implemented");
+        return fail(nullptr, SPH_EINVAL, "unknown math_mode");
+    }
+    if (h->opt.math_mode == SPH_MATH_FAST && h->opt.sweep != SPH_SWEEP_LDS) {
+        delete h;
+        return fail(nullptr, SPH_EINVAL, "SPH_MATH_FAST exists for SPH_SWEEP_LDS only");
     }
     h->n = settings->numParticles;
     h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;

@@ -33,8 +33,15 @@
 
 #define SW_THREADS 256
 #define SW_WAVES (SW_THREADS / SPH_WAVE)
+#ifndef SW_CAP
 #define SW_CAP 256  // staged candidates per chunk per wave (4 KiB)
-#define SW_QCAP 16  // hit-FIFO entries per lane (4 KiB per wave)
+#endif
+#ifndef SW_QCAP
+// hit-FIFO entries per lane (8 KiB per wave).  Measured at n = 4,194,304: 16 entries
+// -> 41 drains per wave at 41 % slot efficiency, 32 -> 32 drains at 53 %; force
+// sweep 2.40 -> 2.34 ms even though the extra LDS costs a resident wave per SIMD.
+#define SW_QCAP 32
+#endif
 
 __device__ __forceinline__ int3 sweep_cell(const DevParams &P, float x, float y,
                                            float z) {
@@ -133,6 +140,42 @@ __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float 
         F.fx += dvx;
         F.fy += dvy;
         F.fz += dvz;
+    }
+}
+
+// ---- SPH_MATH_FAST variants: same formulas, FMA-contracted, with the hardware's
+// approximate reciprocal / reciprocal square root (~1 ulp) instead of the
+// correctly rounded divide and sqrt.  Not bit-identical to the oracle; checked
+// against it at the north star's 1e-5 relative tolerance (tests).
+__device__ __forceinline__ float fast_dist2(float pix, float piy, float piz, float4 pj,
+                                            float &dx, float &dy, float &dz) {
+    dx = pix - pj.x;
+    dy = piy - pj.y;
+    dz = piz - pj.z;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ void force_pair_fast(const DevParams &P, float pix, float piy,
+                                                float piz, float vix, float viy, float viz,
+                                                float prs_i, float4 pj, float4 vj,
+                                                ForceAcc &F) {
+    float dx, dy, dz;
+    const float dist2 = fast_dist2(pix, piy, piz, pj, dx, dy, dz);
+    const float rho_j = vj.w;
+    const float inv_rho = __builtin_amdgcn_rcpf(rho_j);
+    const float prs_j = fmaxf(0.f, rho_j - SPH_REST_DENSITY);
+    const float inv_dist = __builtin_amdgcn_rsqf(dist2);
+    const float dist = dist2 * inv_dist;
+    const bool ok = !(dist2 > P.h2) && !(dist < SPH_EPS_F) && dist2 > 0.f;
+    if (ok) {
+        const float hd = P.h - dist;
+        // fPressure * scale = (-MASS (p_i+p_j) / (2 rho_j)) * (-vcoef (h-r)^2 / r)
+        const float s = (0.5f * SPH_MASS * P.vcoef) * (prs_i + prs_j) * inv_rho * (hd * hd) * inv_dist;
+        // fViscosity = VISCOSITY MASS vcoef (h-r) / rho_j
+        const float fv = (SPH_VISCOSITY * SPH_MASS * P.vcoef) * hd * inv_rho;
+        F.fx = __builtin_fmaf(vj.x - vix, fv, __builtin_fmaf(dx, s, F.fx));
+        F.fy = __builtin_fmaf(vj.y - viy, fv, __builtin_fmaf(dy, s, F.fy));
+        F.fz = __builtin_fmaf(vj.z - viz, fv, __builtin_fmaf(dz, s, F.fz));
     }
 }
 
@@ -393,6 +436,7 @@ __device__ __forceinline__ void wave_walk(const SweepArgs &A, float4 *__restrict
     }
 }
 
+template <bool FAST>
 struct DensityVisitor {
     const DevParams &P;
     float pix, piy, piz;
@@ -401,6 +445,13 @@ struct DensityVisitor {
     // diff = max(h2 - dist2, 0) makes W exactly +0 outside the radius, and adding
     // +0 never changes rho (rho >= +0), so this equals the reference's early return.
     __device__ __forceinline__ void candidate(int, float4 pj) {
+        if (FAST) {
+            float dx, dy, dz;
+            const float dist2 = fast_dist2(pix, piy, piz, pj, dx, dy, dz);
+            const float diff = fmaxf(P.h2 - dist2, 0.f);
+            rho = __builtin_fmaf((SPH_MASS * P.dcoef) * (diff * diff), diff, rho);
+            return;
+        }
         float dx = pix - pj.x;
         float dy = piy - pj.y;
         float dz = piz - pj.z;
@@ -411,6 +462,7 @@ struct DensityVisitor {
     __device__ __forceinline__ void poll() {}
 };
 
+template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -429,7 +481,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
         uint32_t s = wave_sum_u32(pairs);
         if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
     }
-    DensityVisitor V{P, pi.x, pi.y, pi.z, 0.f};
+    DensityVisitor<FAST> V{P, pi.x, pi.y, pi.z, 0.f};
     WalkStamps W;
 #if SW_STAMPS
     asm volatile("" ::"v"(js[0] + je[8]));
@@ -461,6 +513,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
 #define SW_PUSH_BRANCHFREE 1 // measured: force sweep 2.47 ms vs 2.55 ms (n = 4,194,304)
 #endif
 
+template <bool FAST>
 struct ForceVisitor {
     const DevParams &P;
     const SweepArgs &A;
@@ -471,12 +524,14 @@ struct ForceVisitor {
     uint32_t head, tail;
     ForceAcc F;
     unsigned long long drains = 0;
+    uint32_t items = 0; // diagnostic: FIFO entries really evaluated by this lane
 
     __device__ __forceinline__ void candidate(int j, float4 pj) {
         float dx = pix - pj.x;
         float dy = piy - pj.y;
         float dz = piz - pj.z;
-        float dist2 = dx * dx + dy * dy + dz * dz;
+        float dist2 = FAST ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx))
+                           : dx * dx + dy * dy + dz * dz;
 #if SW_PUSH_BRANCHFREE
         // the slot at `tail` is always free here (poll() keeps SW_UNROLL slots
         // spare), so store unconditionally and only advance on a hit
@@ -493,10 +548,11 @@ struct ForceVisitor {
     // in FIFO order.  An empty slot is replaced by the particle itself, whose
     // pair terms are gated off by dist < EPS_F -- an exact no-op.
     __device__ __forceinline__ void drain() {
+        const uint32_t have = tail - head;
 #if SW_STAMPS
         ++drains;
+        items += min(have, (uint32_t)SW_DRAIN);
 #endif
-        const uint32_t have = tail - head;
         uint32_t j[SW_DRAIN];
         float4 pj[SW_DRAIN], vj[SW_DRAIN];
 #pragma unroll
@@ -511,8 +567,10 @@ struct ForceVisitor {
         }
         head += min(have, (uint32_t)SW_DRAIN);
 #pragma unroll
-        for (int u = 0; u < SW_DRAIN; ++u)
-            force_pair(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
+        for (int u = 0; u < SW_DRAIN; ++u) {
+            if (FAST) force_pair_fast(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
+            else force_pair(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
+        }
     }
     __device__ __forceinline__ void poll() {
         // the next trip pushes at most SW_UNROLL entries per lane
@@ -523,6 +581,7 @@ struct ForceVisitor {
     }
 };
 
+template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     __shared__ uint32_t queueAll[SW_WAVES][SW_QCAP * SPH_WAVE];
@@ -536,7 +595,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
     int js[9], je[9];
     load_runs(P, A.cellRange, c, valid, js, je);
-    ForceVisitor V{P, A, queueAll[w], lane, (uint32_t)iSafe, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
+    ForceVisitor<FAST> V{P, A, queueAll[w], lane, (uint32_t)iSafe, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
                    fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY)),
                    0u, 0u, {0.f, 0.f, 0.f}};
     WalkStamps W;
@@ -565,29 +624,35 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
         atomicAdd(S + 10, t4 - t0);  // whole wave
         atomicAdd(S + 11, V.drains); // drain() calls
     }
+    if (A.stampCounter) {
+        uint32_t it = wave_sum_u32(V.items);
+        if (lane == 0) atomicAdd(A.stampCounter + 16 + (blockIdx.x & 255) * 16 + 12, (unsigned long long)it);
+    }
 #endif
 }
 
 void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode, int sweep,
                         hipStream_t s) {
-    (void)mathMode;
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
     if (sweep == 1)
-        k_density_direct<<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_density_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
+    else if (mathMode == 1)
+        k_density_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
     else
-        k_density_lds<<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_density_lds<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
 }
 
 void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode, int sweep,
                       hipStream_t s) {
-    (void)mathMode;
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
     if (sweep == 1)
-        k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
+    else if (mathMode == 1)
+        k_force_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
     else
-        k_force_lds<<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_lds<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
 }
