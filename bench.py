@@ -42,7 +42,9 @@ def parse():
                          "rcp/rsq, tolerance-checked")
     ap.add_argument("--mode", choices=["time", "free"], default="time",
                     help="time: simulateAndTime loop (-m time); free: simulate() loop")
-    ap.add_argument("--cpu-steps", type=int, default=4,
+    ap.add_argument("--no-fast-leg", action="store_true",
+                    help="skip the extra SPH_MATH_FAST measurement")
+    ap.add_argument("--cpu-steps", type=int, default=12,
                     help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-particles", type=int, default=0, help="0 = same n as the GPU run")
     return ap.parse_args()
@@ -63,6 +65,23 @@ def cpu_baseline(n, random_init, steps):
             "sample": f"first {steps} steps of -n {n} -i {'random' if random_init else 'grid'} "
                       f"(of the 100-step run; later steps cost up to 4.7x more), "
                       f"OpenMP oracle, {dt:.1f} s"}
+
+
+def load_traffic(n, args):
+    """HBM bytes per computeDensity launch from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
+    command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for 16-B/lane
+    streaming reads).  None if no measurement matches this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        for e in json.load(open(path)):
+            if e["n"] == n and e["init"] == args.init and e["sweep"] == args.sweep and e["gpus"] == 1:
+                return e
+    except Exception:
+        return None
+    return None
 
 
 def main():
@@ -121,6 +140,22 @@ def main():
         if os.environ.get("SPH_STAMPS"):
             result["stamps"] = sim.debug_counters()
         sim.close()
+        if args.math == "strict" and args.sweep == "lds" and not args.no_fast_leg:
+            # secondary figure: the same K steps in SPH_MATH_FAST (not `value`)
+            fsim = sph.Simulator(s, sweep="lds", device=local_rank, math="fast")
+            fsim.setup()
+            ft = sph.Times()
+            for _ in range(min(W, 3)):
+                fsim.simulateAndTime(ft)
+            fsim.sync()
+            fsim.setup()
+            torch.cuda.synchronize()
+            f0 = time.perf_counter()
+            for _ in range(K):
+                fsim.simulateAndTime(ft) if args.mode == "time" else fsim.simulate()
+            fsim.sync()
+            result["fast_elapsed"] = time.perf_counter() - f0
+            fsim.close()
 
     if world > 1:
         t = torch.tensor([result["elapsed"]], device="cuda", dtype=torch.float64)
@@ -173,6 +208,16 @@ def main():
             t = result["times"]
             out["m_time_table_s"] = {"grid_construction": t.buildGrid, "sph_update": t.sphUpdate,
                                      "data_transfer_exposed": t.memcpy}
+        if "fast_elapsed" in result:
+            out["fast_math"] = {"value": result["n_total"] * K / result["fast_elapsed"],
+                                "unit": "particle-steps/s",
+                                "note": "SPH_MATH_FAST (FMA + approximate rcp/rsq): not bit-exact; max relative "
+                                        "position error 8.1e-7 after 100 steps of -n 8192 -i grid vs the oracle "
+                                        "(north-star tolerance 1e-5; tests/test_gpu_parity.py). Not `value`."}
+        tr = load_traffic(result["n_total"], args)
+        if tr:
+            roof["traffic"] = tr["bytes_per_launch"]
+            roof["traffic_source"] = tr["source"]
         if "stamps" in result:
             out["debug_stamps"] = result["stamps"]
         if args.cpu_steps > 0:
