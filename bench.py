@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("-n", "--particles", type=int, default=4194304,
                     help="BASELINE.json configs[2]: -n 4194304 -i random -m time")
     ap.add_argument("--init", choices=["random", "grid"], default="random")
-    ap.add_argument("--sweep", choices=["lds", "direct"], default="lds")
+    ap.add_argument("--sweep", choices=["list", "lds", "direct"], default="list")
     ap.add_argument("--math", choices=["strict", "fast"], default="strict",
                     help="strict: bit-identical to the oracle (default); fast: FMA + approximate "
                          "rcp/rsq, tolerance-checked")
@@ -140,9 +140,9 @@ def main():
         if os.environ.get("SPH_STAMPS"):
             result["stamps"] = sim.debug_counters()
         sim.close()
-        if args.math == "strict" and args.sweep == "lds" and not args.no_fast_leg:
+        if args.math == "strict" and args.sweep != "direct" and not args.no_fast_leg:
             # secondary figure: the same K steps in SPH_MATH_FAST (not `value`)
-            fsim = sph.Simulator(s, sweep="lds", device=local_rank, math="fast")
+            fsim = sph.Simulator(s, sweep=args.sweep, device=local_rank, math="fast")
             fsim.setup()
             ft = sph.Times()
             for _ in range(min(W, 3)):
@@ -171,8 +171,8 @@ def main():
         n_local = result.get("n_local", n)
         pairs = kt.pair_tests / steps if kt.pair_tests else None
         achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_density_lds (computeDensity)" if args.sweep == "lds"
-                else "k_density_direct", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": {"lds": "k_density_lds", "direct": "k_density_direct",
+                                                   "list": "k_density_mask"}[args.sweep] + " (computeDensity)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": dens_s * 1e6,
                 "algorithmic_bytes_per_launch": DENSITY_BYTES_PER_PARTICLE * n_local,
@@ -193,7 +193,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"-n {result['n_total']} -i {args.init} -m {args.mode}, "
-                                   f"{world}xMI355X, flattened-index radix sort + float4 SoA, "
+                                   f"{world}xMI355X, flattened-index radix sort + float4 SoA, sweep={args.sweep}, "
                                    + ("strict fp32 (bit-identical to the CPU oracle)" if args.math == "strict"
                                       else "FAST fp32 math (FMA, approximate rcp/rsq; 1e-5 tolerance mode)"),
                        "sweep": args.sweep,

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     const float4 *__restrict__ pos_in, const float4 *__restrict__ vel_in,
     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ skeys,
     float4 *__restrict__ pos_out, float4 *__restrict__ vel_out,
-    int2 *__restrict__ cellRange, int n) {
+    float4 *__restrict__ pv8, int2 *__restrict__ cellRange, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool valid = i < n;
@@ -63,19 +63,24 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     if (!valid) return;
     if (i + 1 >= n) knext = 0xFFFFFFFFu;
     uint32_t src = perm[i];
-    pos_out[i] = pos_in[src];
-    vel_out[i] = vel_in[src];
+    const float4 p = pos_in[src], v = vel_in[src];
+    pos_out[i] = p;
+    vel_out[i] = v;
+    if (pv8) { // interleaved copy for the list sweep's force gathers (one line per hit)
+        pv8[2 * (size_t)i] = p;
+        pv8[2 * (size_t)i + 1] = v;
+    }
     if (k != kprev) cellRange[k].x = i;
     if (k != knext) cellRange[k].y = i + 1;
 }
 
 void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                        const uint32_t *perm, const uint32_t *sorted_keys,
-                       float4 *pos_out, float4 *vel_out, int2 *cellRange, int n,
+                       float4 *pos_out, float4 *vel_out, float4 *pv8, int2 *cellRange, int n,
                        hipStream_t s) {
     if (n <= 0) return;
     k_gather_cells<<<(n + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, sorted_keys,
-                                                   pos_out, vel_out, cellRange, n);
+                                                   pos_out, vel_out, pv8, cellRange, n);
 }
 
 __global__ void k_lower_bounds(const uint32_t *__restrict__ keys, int n, Thresholds thr,

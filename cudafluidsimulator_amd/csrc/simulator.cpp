@@ -48,7 +48,8 @@ void Simulator::setup() {
     memset(&o, 0, sizeof o);
     o.struct_size = (int32_t)sizeof o;
     o.device = -1;
-    if (const char *e = getenv("SPH_SWEEP")) o.sweep = (strcmp(e, "direct") == 0) ? SPH_SWEEP_DIRECT : SPH_SWEEP_LDS;
+    if (const char *e = getenv("SPH_SWEEP"))
+        o.sweep = strcmp(e, "direct") == 0 ? SPH_SWEEP_DIRECT : strcmp(e, "lds") == 0 ? SPH_SWEEP_LDS : SPH_SWEEP_LIST;
     int rc = sph_create(&s, &o, &impl);
     check(NULL, rc, "sph_create");
     check(impl, sph_setup(impl), "sph_setup");

@@ -70,6 +70,10 @@ struct sph_handle {
     int ringHead = 0;
     StepEvents *curEv = nullptr;
     SphKernelTimes kt{};
+    float4 *pv8 = nullptr;
+    uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
+    unsigned long long *maskCursor = nullptr;
+    unsigned long long maskCapacity = 0;
     bool external = false;  // pos4/vel4 are caller-owned (sph_bind_buffers)
     hipStream_t ownCompute = nullptr;
     int *boundsDev = nullptr, *boundsHost = nullptr;
@@ -210,6 +214,22 @@ int alloc_device(sph_handle *h) {
     HIPCHK(h, hipMemset(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2)));
     HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
     memset(h->hostPos, 0, posCap * 3 * sizeof(float));
+    if (h->opt.sweep == SPH_SWEEP_LIST) {
+        // 64 mask words (2048 candidates) per particle slot; measured need at
+        // n = 4,194,304 random: 16 words early, 37 at step 100.  A wave that finds
+        // the pool exhausted falls back to testing (sweeps_list.hip).
+        unsigned long long words = (unsigned long long)cap * 64ull;
+        if (words < (1ull << 22)) words = 1ull << 22;
+        if (const char *e = getenv("SPH_MASK_POOL_WORDS")) words = strtoull(e, nullptr, 10);
+        if (words > 0xFFFFFFF0ull) words = 0xFFFFFFF0ull; // offsets are 32-bit
+        h->maskCapacity = words;
+        HIPCHK(h, hipMalloc(&h->maskPool, (size_t)(words ? words : 1) * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->pv8, cap * 2 * sizeof(float4)));
+        HIPCHK(h, hipMalloc(&h->maskOff, cap * sizeof(uint32_t)));
+        HIPCHK(h, hipMemset(h->maskOff, 0xFF, cap * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->maskCursor, sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->maskCursor, 0, sizeof(unsigned long long)));
+    }
     HIPCHK(h, hipMalloc(&h->boundsDev, 8 * sizeof(int)));
     HIPCHK(h, hipHostMalloc(&h->boundsHost, 8 * sizeof(int), hipHostMallocDefault));
     for (auto &pe : h->pairs) {
@@ -307,6 +327,11 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.i_begin = 0;
     A.i_end = h->n;
     A.n_all = h->n;
+    A.maskPool = h->maskPool;
+    A.maskOff = h->maskOff;
+    A.maskCursor = h->maskCursor;
+    A.maskCapacity = h->maskCapacity;
+    A.pv8 = h->pv8;
     return A;
 }
 
@@ -397,7 +422,7 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
     int res = sph_sort_pairs(h->ws, count, key_bits(h), s);
     sph_launch_gather(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
                       h->ws.vals[res], h->ws.keys[res], h->pos4[src_buf ^ 1],
-                      h->vel4[src_buf ^ 1], h->cellRange, count, s);
+                      h->vel4[src_buf ^ 1], h->pv8, h->cellRange, count, s);
     HIPCHK(h, hipEventRecord(pe->b, s));
     if (nthr > 0) {
         Thresholds T{};
@@ -427,6 +452,7 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     A.force_out = nullptr;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
     PairEvent *pe = nullptr;
+    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, sizeof(unsigned long long), h->compute));
     if ((rc = pair_begin(h, &h->kt.density, &pe))) return rc;
     sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
     HIPCHK(h, hipEventRecord(pe->b, h->compute));
@@ -517,9 +543,13 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
         delete h;
         return fail(nullptr, SPH_EINVAL, "unknown math_mode");
     }
-    if (h->opt.math_mode == SPH_MATH_FAST && h->opt.sweep != SPH_SWEEP_LDS) {
+    if (h->opt.sweep < SPH_SWEEP_LIST || h->opt.sweep > SPH_SWEEP_LDS) {
         delete h;
-        return fail(nullptr, SPH_EINVAL, "SPH_MATH_FAST exists for SPH_SWEEP_LDS only");
+        return fail(nullptr, SPH_EINVAL, "unknown sweep variant");
+    }
+    if (h->opt.math_mode == SPH_MATH_FAST && h->opt.sweep == SPH_SWEEP_DIRECT) {
+        delete h;
+        return fail(nullptr, SPH_EINVAL, "SPH_MATH_FAST does not exist for SPH_SWEEP_DIRECT");
     }
     h->n = settings->numParticles;
     h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
@@ -571,6 +601,10 @@ void sph_destroy(sph_handle *h) {
         for (auto &e : se.e) if (e) (void)hipEventDestroy(e);
         for (auto &e : se.c) if (e) (void)hipEventDestroy(e);
     }
+    if (h->pv8) (void)hipFree(h->pv8);
+    if (h->maskPool) (void)hipFree(h->maskPool);
+    if (h->maskOff) (void)hipFree(h->maskOff);
+    if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
     if (h->boundsHost) (void)hipHostFree(h->boundsHost);
     for (auto &pe : h->pairs) {
@@ -612,7 +646,7 @@ int sph_phase_grid(sph_handle *h) {
     int res = sph_sort_pairs(h->ws, n, key_bits(h), s);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
     sph_launch_gather(h->pos4[c], h->vel4[c], h->ws.vals[res], h->ws.keys[res],
-                      h->pos4[c ^ 1], h->vel4[c ^ 1], h->cellRange, n, s);
+                      h->pos4[c ^ 1], h->vel4[c ^ 1], h->pv8, h->cellRange, n, s);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[3], s));
     HIPCHK(h, hipGetLastError());
     h->sorted = c ^ 1;
@@ -627,6 +661,7 @@ int sph_phase_density(sph_handle *h) {
     if (h->phase != 1) return fail(h, SPH_ESTATE, "density phase needs the grid phase first");
     SweepArgs A = make_sweep_args(h);
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
+    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, sizeof(unsigned long long), h->compute));
     sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
     if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->e[4], h->compute));
     HIPCHK(h, hipGetLastError());

@@ -62,7 +62,7 @@ void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
                      uint32_t *vals, int n, hipStream_t s);
 void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                        const uint32_t *perm, const uint32_t *sorted_keys,
-                       float4 *pos_out, float4 *vel_out, int2 *cellRange, int n,
+                       float4 *pos_out, float4 *vel_out, float4 *pv8, int2 *cellRange, int n,
                        hipStream_t s);
 // bounds[k] = #keys < thr[k] over sorted keys (one binary search per lane)
 struct Thresholds { uint32_t v[8]; };
@@ -85,7 +85,15 @@ struct SweepArgs {
     unsigned long long *stampCounter; // diagnostic builds only (same buffer)
     int i_begin, i_end;       // owned range (whole array for one domain)
     int n_all;
+    // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
+    uint32_t *maskPool;               // pool of 32-candidate mask words
+    uint32_t *maskOff;                // per sorted particle: first word, or ~0u
+    unsigned long long *maskCursor;   // words handed out this step
+    unsigned long long maskCapacity;  // pool size in words
+    float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
 };
+void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s);
+void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s);
 void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode,
                         int sweep, hipStream_t s);
 void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode,

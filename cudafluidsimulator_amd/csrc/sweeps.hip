@@ -29,213 +29,7 @@
 // order, so every particle still accumulates its neighbours in canonical
 // order, and skipped candidates contribute exactly +-0 in the reference, which
 // never changes an accumulator that is not -0 (it never is: sums start at +0).
-#include "sph_device.h"
-
-#define SW_THREADS 256
-#define SW_WAVES (SW_THREADS / SPH_WAVE)
-#ifndef SW_CAP
-#define SW_CAP 256  // staged candidates per chunk per wave (4 KiB)
-#endif
-#ifndef SW_QCAP
-// hit-FIFO entries per lane (8 KiB per wave).  Measured at n = 4,194,304: 16 entries
-// -> 41 drains per wave at 41 % slot efficiency, 32 -> 32 drains at 53 %; force
-// sweep 2.40 -> 2.34 ms even though the extra LDS costs a resident wave per SIMD.
-#define SW_QCAP 32
-#endif
-
-__device__ __forceinline__ int3 sweep_cell(const DevParams &P, float x, float y,
-                                           float z) {
-    int3 c;
-    c.x = min(max((int)(x / P.h), 0), P.D - 1);
-    c.y = min(max((int)(y / P.h), 0), P.D - 1);
-    c.z = min(max((int)(z / P.h), 0), P.D - 1);
-    return c;
-}
-
-// The nine runs of one particle: [js[r], je[r]) in sorted-stream indices,
-// r = (dz+1)*3 + (dy+1).  Empty runs are {0,0}.
-__device__ __forceinline__ void load_runs(const DevParams &P,
-                                          const int2 *__restrict__ cellRange,
-                                          int3 c, bool valid, int (&js)[9],
-                                          int (&je)[9]) {
-    const int x0 = max(c.x - 1, 0), x1 = min(c.x + 1, P.D - 1);
-    const int xm = min(x0 + 1, x1);
-    // All 27 table reads are issued before any is used (rows outside the grid are
-    // clamped for the load and discarded afterwards): one L2 round trip per
-    // particle instead of nine dependent ones.
-    int2 r0[9], r1[9], r2[9];
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int sz = min(max(c.z + (r / 3 - 1), 0), P.D - 1);
-        const int sy = min(max(c.y + (r % 3 - 1), 0), P.D - 1);
-        const int base = sy * P.D + sz * P.D * P.D;
-        r0[r] = cellRange[base + x0];
-        r1[r] = cellRange[base + xm];
-        r2[r] = cellRange[base + x1];
-    }
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int sz = c.z + (r / 3 - 1), sy = c.y + (r % 3 - 1);
-        const bool inGrid = valid && sy >= 0 && sy < P.D && sz >= 0 && sz < P.D;
-        const bool n0 = r0[r].y > r0[r].x, n1 = r1[r].y > r1[r].x, n2 = r2[r].y > r2[r].x;
-        const bool any = inGrid && (n0 | n1 | n2);
-        const int s = n0 ? r0[r].x : (n1 ? r1[r].x : r2[r].x);
-        const int e = n2 ? r2[r].y : (n1 ? r1[r].y : r0[r].y);
-        js[r] = any ? s : 0;
-        je[r] = any ? e : 0;
-    }
-}
-
-// ---- per-pair arithmetic (strict: individually rounded, reference order) ----
-
-// densityKernel (simulator.cu:84-97) folded with `density += MASS * W` (:179).
-__device__ __forceinline__ void density_pair(const DevParams &P, float pix, float piy,
-                                             float piz, float4 pj, float &rho) {
-    float dx = pix - pj.x;
-    float dy = piy - pj.y;
-    float dz = piz - pj.z;
-    float dist2 = dx * dx + dy * dy + dz * dz;
-    if (!(dist2 > P.h2)) {
-        float diff = P.h2 - dist2;
-        rho += SPH_MASS * (P.dcoef * diff * diff * diff);
-    }
-}
-
-struct ForceAcc {
-    float fx, fy, fz;
-};
-
-// One neighbour of kernelUpdateForces (simulator.cu:223-251) with
-// pressureKernel (:99-117) and viscosityKernel (:119-130) inlined.
-__device__ __forceinline__ void force_pair(const DevParams &P, float pix, float piy,
-                                           float piz, float vix, float viy, float viz,
-                                           float prs_i, float4 pj, float4 vj,
-                                           ForceAcc &F) {
-    float dx = pix - pj.x;
-    float dy = piy - pj.y;
-    float dz = piz - pj.z;
-    float dist2 = dx * dx + dy * dy + dz * dz;
-    float rho_j = vj.w;
-    float prs_j = fmaxf(0.f, SPH_GAS_CONSTANT * (rho_j - SPH_REST_DENSITY));
-    float dist = sqrtf(dist2);
-    bool tiny = dist < SPH_EPS_F;
-    if (!(dist2 > P.h2) && !tiny) {
-        float fPressure = -SPH_MASS * (prs_i + prs_j) / (2.f * rho_j);
-        float scale = (-P.vcoef) * (P.h - dist) * (P.h - dist) / dist;
-        float kx = dx * scale, ky = dy * scale, kz = dz * scale;
-        kx *= fPressure;
-        ky *= fPressure;
-        kz *= fPressure;
-        F.fx += kx;
-        F.fy += ky;
-        F.fz += kz;
-    }
-    if (!(dist > P.h) && !tiny) {
-        float fViscosity =
-            SPH_VISCOSITY * SPH_MASS * (P.vcoef * (P.h - dist)) / rho_j;
-        float dvx = vj.x - vix, dvy = vj.y - viy, dvz = vj.z - viz;
-        dvx *= fViscosity;
-        dvy *= fViscosity;
-        dvz *= fViscosity;
-        F.fx += dvx;
-        F.fy += dvy;
-        F.fz += dvz;
-    }
-}
-
-// ---- SPH_MATH_FAST variants: same formulas, FMA-contracted, with the hardware's
-// approximate reciprocal / reciprocal square root (~1 ulp) instead of the
-// correctly rounded divide and sqrt.  Not bit-identical to the oracle; checked
-// against it at the north star's 1e-5 relative tolerance (tests).
-__device__ __forceinline__ float fast_dist2(float pix, float piy, float piz, float4 pj,
-                                            float &dx, float &dy, float &dz) {
-    dx = pix - pj.x;
-    dy = piy - pj.y;
-    dz = piz - pj.z;
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-}
-
-__device__ __forceinline__ void force_pair_fast(const DevParams &P, float pix, float piy,
-                                                float piz, float vix, float viy, float viz,
-                                                float prs_i, float4 pj, float4 vj,
-                                                ForceAcc &F) {
-    float dx, dy, dz;
-    const float dist2 = fast_dist2(pix, piy, piz, pj, dx, dy, dz);
-    const float rho_j = vj.w;
-    const float inv_rho = __builtin_amdgcn_rcpf(rho_j);
-    const float prs_j = fmaxf(0.f, rho_j - SPH_REST_DENSITY);
-    const float inv_dist = __builtin_amdgcn_rsqf(dist2);
-    const float dist = dist2 * inv_dist;
-    const bool ok = !(dist2 > P.h2) && !(dist < SPH_EPS_F) && dist2 > 0.f;
-    if (ok) {
-        const float hd = P.h - dist;
-        // fPressure * scale = (-MASS (p_i+p_j) / (2 rho_j)) * (-vcoef (h-r)^2 / r)
-        const float s = (0.5f * SPH_MASS * P.vcoef) * (prs_i + prs_j) * inv_rho * (hd * hd) * inv_dist;
-        // fViscosity = VISCOSITY MASS vcoef (h-r) / rho_j
-        const float fv = (SPH_VISCOSITY * SPH_MASS * P.vcoef) * hd * inv_rho;
-        F.fx = __builtin_fmaf(vj.x - vix, fv, __builtin_fmaf(dx, s, F.fx));
-        F.fy = __builtin_fmaf(vj.y - viy, fv, __builtin_fmaf(dy, s, F.fy));
-        F.fz = __builtin_fmaf(vj.z - viz, fv, __builtin_fmaf(dz, s, F.fz));
-    }
-}
-
-// kernelUpdatePositions (simulator.cu:258-318).
-__device__ __forceinline__ void integrate_particle(const DevParams &P, float4 &p,
-                                                   float &vx, float &vy, float &vz,
-                                                   const ForceAcc &F, float density) {
-    const float timestep = P.dt;
-    vx += timestep * F.fx / density;
-    vy += timestep * (F.fy / density + SPH_GRAVITY);
-    vz += timestep * F.fz / density;
-
-    p.x += timestep * vx;
-    p.y += timestep * vy;
-    p.z += timestep * vz;
-
-    if (p.x < P.h) { p.x = P.h; vx *= -SPH_ELASTICITY; }
-    else if (p.x > P.boxHi) { p.x = P.boxHi; vx *= -SPH_ELASTICITY; }
-    if (p.y < P.h) { p.y = P.h; vy *= -SPH_ELASTICITY; }
-    else if (p.y > P.boxHi) { p.y = P.boxHi; vy *= -SPH_ELASTICITY; }
-    if (p.z < P.h) { p.z = P.h; vz *= -SPH_ELASTICITY; }
-    else if (p.z > P.boxHi) { p.z = P.boxHi; vz *= -SPH_ELASTICITY; }
-
-    if (fabsf(vx) < SPH_EPS_F) vx = 0;
-    if (fabsf(vy) < SPH_EPS_F) vy = 0;
-    if (fabsf(vz) < SPH_EPS_F) vz = 0;
-}
-
-__device__ __forceinline__ void store_particle(const SweepArgs &A, int i, float4 p,
-                                               float vx, float vy, float vz,
-                                               float rho, const ForceAcc &F) {
-    A.pos_out[i] = p;
-    A.vel_out[i] = make_float4(vx, vy, vz, rho);
-    if (A.host_order_pos) {
-        // devicePosition[pIdx] = position (simulator.cu:317): original-id order
-        uint32_t id = __float_as_uint(p.w);
-        float *o = A.host_order_pos + 3 * (size_t)id;
-        o[0] = p.x;
-        o[1] = p.y;
-        o[2] = p.z;
-    }
-    if (A.force_out) A.force_out[i] = make_float4(F.fx, F.fy, F.fz, 0.f);
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2),
-// so consecutive blockIdx values land on different XCDs.  Consecutive tiles of
-// the cell-sorted stream share most of their neighbour window; remap so that
-// every XCD walks ONE contiguous eighth of the stream and its L2 sees each
-// window once (speed only -- any placement gives the same result).
-__device__ __forceinline__ int xcd_tile(int b, int nb) {
-    const int xcd = b & 7, idx = b >> 3;
-    const int q = nb >> 3, rem = nb & 7;
-    return xcd * q + min(xcd, rem) + idx;
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+#include "sweep_common.h"
 
 // =====================  DIRECT variant (check path)  =========================
 __global__ __launch_bounds__(SW_THREADS) void k_density_direct(DevParams P,
@@ -313,7 +107,6 @@ struct WalkStamps {
     unsigned long long stage = 0, test = 0;
 };
 
-#define SW_UNROLL 4
 #ifndef SW_PIPELINE
 #define SW_PIPELINE 1
 #endif
@@ -636,7 +429,9 @@ void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode, in
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-    if (sweep == 1)
+    if (sweep == 0)
+        sph_launch_density_list(P, A, mathMode, s);
+    else if (sweep == 1)
         k_density_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
     else if (mathMode == 1)
         k_density_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
@@ -649,7 +444,9 @@ void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode, int 
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-    if (sweep == 1)
+    if (sweep == 0)
+        sph_launch_force_list(P, A, mathMode, s);
+    else if (sweep == 1)
         k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
     else if (mathMode == 1)
         k_force_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);

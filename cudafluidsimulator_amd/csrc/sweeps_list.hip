@@ -1,0 +1,380 @@
+// SPH_SWEEP_LIST: density sweep that RECORDS which candidates are inside the
+// support radius, and a force sweep that walks only those.
+//
+// kernelUpdatePressureAndDensity (simulator.cu:149-190) and kernelUpdateForces
+// (simulator.cu:192-256) test exactly the same candidate pairs against the same
+// radius, one kernel after the other, and ~85 % of those tests fail.  Here the
+// density sweep leaves one bit per candidate (bit b of word w of run r <=> sorted
+// index js[r] + 32 w + b) in a per-particle bit stream; the force sweep pops set
+// bits in ascending order -- the canonical summation order -- and evaluates the
+// pair body for hits only.  It needs no distance tests, no LDS and few
+// registers, so it runs at high occupancy, and its wave iterations are the
+// maximum hit COUNT over the wave's lanes rather than the maximum candidate
+// count.
+//
+// Bit streams live in a pool (mask words) carved up per wave with one atomicAdd;
+// a wave that finds the pool exhausted marks its particles and the force sweep
+// falls back to testing every candidate for them (same results, slower).
+//
+// MUST be compiled with -ffp-contract=off (see sweep_common.h).
+#include "sweep_common.h"
+
+#define SL_NONE 0xFFFFFFFFu
+#ifndef SL_PV8
+#define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
+                 // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
+#endif
+#ifndef SL_DIRECT_MASKS
+#define SL_DIRECT_MASKS 0 // 1: one-thread-per-particle mask builder (A/B and fallback study)
+#endif
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < SPH_WAVE; off <<= 1) {
+        uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// density + hit masks.  One thread per particle, candidates straight from
+// global memory (neighbouring lanes read the same few cache lines).
+// ---------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(SW_THREADS) void k_density_mask(DevParams P, SweepArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const bool valid = i < A.i_end;
+    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, valid, js, je);
+
+    // carve this wave's slice of the mask pool
+    uint32_t words = 0, pairs = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        words += (uint32_t)(je[r] - js[r] + 31) >> 5;
+        pairs += (uint32_t)(je[r] - js[r]);
+    }
+    const uint32_t incl = wave_incl_scan_u32(words, lane);
+    const uint32_t total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(A.maskCursor, (unsigned long long)total);
+    base = (unsigned long long)__shfl((unsigned)(base >> 32), 0) << 32 |
+           (unsigned long long)__shfl((unsigned)base, 0);
+    const bool ok = base + total <= A.maskCapacity; // wave-uniform
+    uint32_t off = ok ? (uint32_t)base + (incl - words) : SL_NONE;
+    if (valid) A.maskOff[i] = off;
+    if (A.pairCounter) {
+        uint32_t s = wave_sum_u32(pairs);
+        if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
+    }
+
+    float rho = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int len = je[r] - js[r];
+        for (int k0 = 0; k0 < len; k0 += 32) {
+            uint32_t m = 0;
+            const int kn = min(32, len - k0);
+            const float4 *cand = A.pos4 + js[r] + k0;
+#pragma unroll 4
+            for (int b = 0; b < kn; ++b) {
+                const float4 pj = cand[b];
+                float dx = pi.x - pj.x;
+                float dy = pi.y - pj.y;
+                float dz = pi.z - pj.z;
+                float dist2;
+                if (FAST) {
+                    dist2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    const float diff = fmaxf(P.h2 - dist2, 0.f);
+                    rho = __builtin_fmaf((SPH_MASS * P.dcoef) * (diff * diff), diff, rho);
+                } else {
+                    dist2 = dx * dx + dy * dy + dz * dz;
+                    const float diff = fmaxf(P.h2 - dist2, 0.f);
+                    rho += SPH_MASS * (P.dcoef * diff * diff * diff);
+                }
+                // a "hit" is any candidate for which a force term can be non-zero
+                m |= (!(dist2 > P.cut2) ? 1u : 0u) << b;
+            }
+            if (ok) A.maskPool[off++] = m;
+        }
+    }
+    if (valid) {
+        rho = fmaxf(rho, SPH_EPS_F);
+        A.vel4[i].w = rho;
+        A.pv8[2 * (size_t)i + 1].w = rho;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// density + hit masks, LDS-staged (production).  Same wave-autonomous walk as
+// k_density_lds: the wave stages the union of its lanes' ranges of one run in
+// LDS and every lane walks its own range from its first candidate, four per
+// trip.  All lanes of the wave are at the same candidate ORDINAL k at any time,
+// so the mask bit position (k & 31) is wave-uniform: recording a hit costs a
+// compare, a select of a scalar bit and an OR, and whole words are flushed every
+// eighth trip.  A run whose union does not fit the slice (dense cells) is walked
+// in the same lock-step straight from global memory.
+// ---------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, SweepArgs A) {
+    __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 *stage = stageAll[w];
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const bool valid = i < A.i_end;
+    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, valid, js, je);
+
+    uint32_t words = 0, pairs = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        words += (uint32_t)(je[r] - js[r] + 31) >> 5;
+        pairs += (uint32_t)(je[r] - js[r]);
+    }
+    const uint32_t incl = wave_incl_scan_u32(words, lane);
+    const uint32_t total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(A.maskCursor, (unsigned long long)total);
+    base = (unsigned long long)__shfl((unsigned)(base >> 32), 0) << 32 |
+           (unsigned long long)__shfl((unsigned)base, 0);
+    const bool ok = base + total <= A.maskCapacity; // wave-uniform
+    uint32_t woff = ok ? (uint32_t)base + (incl - words) : SL_NONE;
+    if (valid) A.maskOff[i] = woff;
+    if (A.pairCounter) {
+        uint32_t s = wave_sum_u32(pairs);
+        if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
+    }
+
+    if (lane < SW_UNROLL) stage[SW_CAP + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    const float4 *const sent = stage + SW_CAP;
+    float rho = 0.f;
+    const int rowId = c.y + c.z * P.D;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int rowL = __builtin_amdgcn_readlane(rowId, leader);
+        const bool act = valid && rowId == rowL;
+        todo &= ~__ballot(act);
+#pragma unroll 1
+        for (int r = 0; r < 9; ++r) {
+            int jsr = js[0], jer = je[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) { // r is wave-uniform: scalar-conditioned moves
+                jsr = (r == q) ? js[q] : jsr;
+                jer = (r == q) ? je[q] : jer;
+            }
+            const bool nonempty = act && jer > jsr;
+            const unsigned long long mm = __ballot(nonempty);
+            if (!mm) continue;
+            const int lo = __ffsll((long long)mm) - 1;
+            const int hi = 63 - __clzll((long long)mm);
+            const int u0 = __builtin_amdgcn_readlane(jsr, lo);
+            const int u1 = __builtin_amdgcn_readlane(jer, hi);
+            const int len = nonempty ? jer - jsr : 0;          // this lane's candidates
+            const int nwords = (len + 31) >> 5;                // and mask words for this run
+            const bool staged = (u1 - u0) <= SW_CAP;           // wave-uniform
+            if (staged) {
+                for (int k = lane; k < u1 - u0; k += SPH_WAVE) stage[k] = A.pos4[u0 + k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const float4 *cur = stage + (nonempty ? jsr - u0 : 0);
+            const float4 *gcur = A.pos4 + (nonempty ? jsr : 0);
+            uint32_t m = 0;
+            int k = 0;
+            for (; __ballot(k < len); k += SW_UNROLL) {
+                float4 pj[SW_UNROLL];
+                if (staged) {
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) {
+                        const float4 *p = (k + u < len) ? cur + k : sent;
+                        pj[u] = p[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) {
+                        const bool in = k + u < len;
+                        pj[u] = gcur[in ? k + u : 0];
+                        pj[u].x = in ? pj[u].x : 1e18f; // out of range: fails every radius test
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SW_UNROLL; ++u) {
+                    float dx = pi.x - pj[u].x;
+                    float dy = pi.y - pj[u].y;
+                    float dz = pi.z - pj[u].z;
+                    float dist2;
+                    if (FAST) {
+                        dist2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        const float diff = fmaxf(P.h2 - dist2, 0.f);
+                        rho = __builtin_fmaf((SPH_MASS * P.dcoef) * (diff * diff), diff, rho);
+                    } else {
+                        dist2 = dx * dx + dy * dy + dz * dz;
+                        const float diff = fmaxf(P.h2 - dist2, 0.f);
+                        rho += SPH_MASS * (P.dcoef * diff * diff * diff);
+                    }
+                    const uint32_t bit = 1u << ((k + u) & 31); // wave-uniform
+                    m |= !(dist2 > P.cut2) ? bit : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
+                if (((k + SW_UNROLL) & 31) == 0) { // a whole word is complete (wave-uniform)
+                    const int widx = k >> 5;
+                    if (ok && widx < nwords) A.maskPool[woff + widx] = m;
+                    m = 0;
+                }
+            }
+            if ((k & 31) != 0) { // last, partial word
+                const int widx = k >> 5;
+                if (ok && widx < nwords) A.maskPool[woff + widx] = m;
+            }
+            if (ok) woff += (uint32_t)nwords;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (valid) {
+        rho = fmaxf(rho, SPH_EPS_F);
+        A.vel4[i].w = rho;
+        A.pv8[2 * (size_t)i + 1].w = rho;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// force + integrate over the recorded hits
+// ---------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(SW_THREADS) void k_force_list(DevParams P, SweepArgs A) {
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const bool valid = i < A.i_end;
+    const int iSafe = valid ? i : A.i_begin;
+    float4 pi = A.pos4[iSafe];
+    const float4 vi = A.vel4[iSafe];
+    const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, valid, js, je);
+    const uint32_t off = valid ? A.maskOff[i] : 0u;
+    ForceAcc F = {0.f, 0.f, 0.f};
+
+    if (__ballot(valid && off == SL_NONE)) {
+        // pool was exhausted for this wave: test every candidate (check-path code)
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+            for (int j = js[r]; j < je[r]; ++j) {
+                if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+                else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+            }
+    } else {
+        // word index -> first candidate of that word: 32*wi + adj[run(wi)], where
+        // cw[r] = words before run r.  (Static indexing only: nothing spills.)
+        int cw[10], adj[9];
+        cw[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            cw[r + 1] = cw[r] + ((je[r] - js[r] + 31) >> 5);
+            adj[r] = js[r] - 32 * cw[r];
+        }
+        const int total = cw[9];
+        auto base_of = [&](int wi) {
+            int a = adj[0];
+#pragma unroll
+            for (int r = 1; r < 9; ++r) a = (wi >= cw[r]) ? adj[r] : a;
+            return 32 * wi + a;
+        };
+        const uint32_t *stream = A.maskPool + off;
+        // Bit cursor.  m: bits of the current word; mn: the next word, already in
+        // flight.  pop() returns the next hit's sorted index, or the particle itself
+        // once the stream is exhausted (dist = 0 gates every term: exact no-op).
+        int wi = 0;
+        uint32_t m = 0, mn = 0;
+        int jb = 0, jbn = 0;
+        bool live = true;
+        if (wi < total) { mn = stream[wi]; jbn = base_of(wi); ++wi; }
+        auto pop = [&]() -> int {
+            if (m == 0) { // take the prefetched word, start fetching the one after
+                m = mn;
+                jb = jbn;
+                mn = 0;
+                if (wi < total) { mn = stream[wi]; jbn = base_of(wi); ++wi; }
+            }
+            live = (m | mn) != 0 || wi < total;
+            const bool has = m != 0;
+            const int b = has ? __builtin_ctz(m) : 0;
+            m &= m - 1u; // (0 stays 0)
+            return has ? jb + b : iSafe;
+        };
+        auto body = [&](const float4 &pj, const float4 &vj) {
+            if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
+            else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
+        };
+        // Two gathers are always in flight while a pair body is evaluated: the
+        // loop is unrolled by two so the pipeline registers never move.
+#if SL_PV8
+#define SL_POS(j) A.pv8[2 * (size_t)(j)]
+#define SL_VEL(j) A.pv8[2 * (size_t)(j) + 1]
+#else
+#define SL_POS(j) A.pos4[j]
+#define SL_VEL(j) A.vel4[j]
+#endif
+        int j0 = pop();
+        float4 p0 = SL_POS(j0), v0 = SL_VEL(j0);
+        int j1 = pop();
+        float4 p1 = SL_POS(j1), v1 = SL_VEL(j1);
+        for (;;) {
+            body(p0, v0);
+            j0 = pop();
+            if (!__ballot(live)) { body(p1, v1); p0 = SL_POS(j0); v0 = SL_VEL(j0); body(p0, v0); break; }
+            p0 = SL_POS(j0);
+            v0 = SL_VEL(j0);
+            body(p1, v1);
+            j1 = pop();
+            if (!__ballot(live)) { body(p0, v0); p1 = SL_POS(j1); v1 = SL_VEL(j1); body(p1, v1); break; }
+            p1 = SL_POS(j1);
+            v1 = SL_VEL(j1);
+        }
+    }
+    if (valid) {
+        float vx = vi.x, vy = vi.y, vz = vi.z;
+        integrate_particle(P, pi, vx, vy, vz, F, vi.w);
+        store_particle(A, i, pi, vx, vy, vz, vi.w, F);
+    }
+}
+
+void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
+    int cnt = A.i_end - A.i_begin;
+    if (cnt <= 0) return;
+    int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
+#if SL_DIRECT_MASKS
+    if (mathMode == 1) k_density_mask<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    else k_density_mask<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+#else
+    if (mathMode == 1) k_density_mask_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    else k_density_mask_lds<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+#endif
+}
+
+// Slab path: rho (and velocity) of HALO particles arrive in vel4 through exchange
+// B after the density sweep; mirror them into the interleaved records.
+__global__ void k_patch_pv8(const float4 *__restrict__ vel4, float4 *__restrict__ pv8, int i_begin,
+                            int i_end, int n_all) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = t < i_begin ? t : i_end + (t - i_begin);
+    if (j < n_all) pv8[2 * (size_t)j + 1] = vel4[j];
+}
+
+void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
+    int cnt = A.i_end - A.i_begin;
+    if (cnt <= 0) return;
+    int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
+    const int halo = A.i_begin + (A.n_all - A.i_end);
+    if (halo > 0) k_patch_pv8<<<(halo + 255) / 256, 256, 0, s>>>(A.vel4, A.pv8, A.i_begin, A.i_end, A.n_all);
+    if (mathMode == 1) k_force_list<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    else k_force_list<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+}

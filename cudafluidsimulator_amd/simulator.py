@@ -45,7 +45,7 @@ def _fp(a):
 
 
 class Simulator:
-    def __init__(self, settings, sweep="lds", flags=0, device=-1, capacity=0, math="strict"):
+    def __init__(self, settings, sweep="list", flags=0, device=-1, capacity=0, math="strict"):
         self.settings = settings
         self._L = load_library()
         self._h = C.c_void_p()
@@ -53,7 +53,7 @@ class Simulator:
         self._opt.struct_size = C.sizeof(SphOptions)
         self._opt.device = device
         self._opt.math_mode = _lib.SPH_MATH_FAST if math == "fast" else _lib.SPH_MATH_STRICT
-        self._opt.sweep = _lib.SPH_SWEEP_DIRECT if sweep == "direct" else _lib.SPH_SWEEP_LDS
+        self._opt.sweep = _lib.SWEEPS[sweep]
         self._opt.flags = flags
         self._opt.capacity = capacity
         rc = self._L.sph_create(C.byref(settings), C.byref(self._opt), C.byref(self._h))

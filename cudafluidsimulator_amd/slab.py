@@ -75,7 +75,7 @@ def layer_of(pos_z, h, D):
 class HipSlabBackend:
     """Kernels of libsph_hip.so on ranges of four torch-owned float4 buffers."""
 
-    def __init__(self, settings, capacity, device=0, sweep="lds", flags=0):
+    def __init__(self, settings, capacity, device=0, sweep="list", flags=0):
         self.settings = settings
         self.cap = int(capacity)
         self.device = torch.device("cuda", device)
@@ -87,7 +87,7 @@ class HipSlabBackend:
         opt.struct_size = C.sizeof(SphOptions)
         opt.device = device
         opt.math_mode = _lib.SPH_MATH_STRICT
-        opt.sweep = _lib.SPH_SWEEP_DIRECT if sweep == "direct" else _lib.SPH_SWEEP_LDS
+        opt.sweep = _lib.SWEEPS[sweep]
         opt.flags = flags | _lib.SPH_FLAG_EXTERNAL_STATE | _lib.SPH_FLAG_NO_READBACK
         opt.capacity = self.cap
         self._h = C.c_void_p()

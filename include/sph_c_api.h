@@ -59,8 +59,10 @@ enum {
     SPH_MATH_FAST = 1    /* FMA contraction + approximate rcp/sqrt (tolerance-checked) */
 };
 enum {
-    SPH_SWEEP_LDS = 0,   /* LDS-staged neighbour window (production) */
-    SPH_SWEEP_DIRECT = 1 /* one thread per particle, direct global loads (check) */
+    SPH_SWEEP_LIST = 0,   /* production: LDS-staged density sweep records one hit bit per
+                             candidate, the force sweep walks the recorded hits */
+    SPH_SWEEP_DIRECT = 1, /* check path: one thread per particle, direct global loads */
+    SPH_SWEEP_LDS = 2     /* LDS-staged window in both sweeps, hit FIFO in the force sweep */
 };
 enum {
     SPH_FLAG_COUNT_PAIRS = 1, /* accumulate the candidate pair-test count per step */

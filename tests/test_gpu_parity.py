@@ -15,10 +15,10 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-SWEEPS = ["lds", "direct"]
+SWEEPS = ["list", "lds", "direct"]
 
 
-def make_pair(n, random_init, sweep="lds", flags=0, pos=None, vel=None):
+def make_pair(n, random_init, sweep="list", flags=0, pos=None, vel=None):
     s = sph.default_settings(n, random_init)
     sim = sph.Simulator(s, sweep=sweep, flags=flags)
     ref = O.OracleSim(n, random_init)
@@ -212,6 +212,19 @@ def test_fast_math_mode_within_north_star_tolerance():
     g, r = sim.download_state(), ref.download()
     assert np.allclose(g["rho"], r["rho"], rtol=1e-5)
     assert np.allclose(g["pos"], r["pos"], rtol=1e-5, atol=1e-7)
+    sim.close()
+
+
+def test_list_sweep_pool_exhaustion_falls_back(monkeypatch):
+    """A mask pool that is too small must only cost speed: waves that find it
+    exhausted mark their particles and the force sweep tests every candidate."""
+    pos, vel = clustered_state(30000, 23)
+    monkeypatch.setenv("SPH_MASK_POOL_WORDS", "20000")  # far too few words
+    sim, ref = make_pair(len(pos), False, "list", pos=pos, vel=vel)
+    monkeypatch.delenv("SPH_MASK_POOL_WORDS")
+    for _ in range(3):
+        sim.simulate(); ref.step()
+    compare_state(sim, ref, "tiny pool")
     sim.close()
 
 

@@ -11,7 +11,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run(n, steps, sweep="lds", flags=0):
+def run(n, steps, sweep="list", flags=0):
     sim = sph.Simulator(sph.default_settings(n, True), sweep=sweep, flags=flags)
     sim.setup()
     for _ in range(steps):
@@ -19,12 +19,15 @@ def run(n, steps, sweep="lds", flags=0):
     return sim
 
 
-def test_config2_262144_lds_equals_direct_and_oracle():
-    a = run(262144, 12, "lds", _lib.SPH_FLAG_COUNT_PAIRS)
+def test_config2_262144_all_sweeps_equal_and_oracle():
+    a = run(262144, 12, "list", _lib.SPH_FLAG_COUNT_PAIRS)
     b = run(262144, 12, "direct")
-    sa, sb = a.download_state(), b.download_state()
+    c = run(262144, 12, "lds")
+    sa, sb, sc = a.download_state(), b.download_state(), c.download_state()
     for k in sa:
         assert_bit_equal(sa[k], sb[k], k)
+        assert_bit_equal(sa[k], sc[k], k + " (lds)")
+    c.close()
     ref = O.OracleSim(262144, True)
     ref.setup(); ref.step(12)
     assert_bit_equal(sa["pos"], ref.download()["pos"], "oracle")

@@ -124,8 +124,9 @@ def test_gloo_slabs_equal_single_domain(world, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sweep", ["list", "lds"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_hip_loopback_slabs_equal_single_domain(world):
+def test_hip_loopback_slabs_equal_single_domain(world, sweep):
     n, steps = 60000, 8
     pos, vel = moving_state(n, 5)
     settings = sph.default_settings(n, False)
@@ -133,7 +134,7 @@ def test_hip_loopback_slabs_equal_single_domain(world):
     bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
     slabs = []
     for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
-        sl = S.Slab(S.HipSlabBackend(settings, n, device=0), r, world, zlo, zhi, 100)
+        sl = S.Slab(S.HipSlabBackend(settings, n, device=0, sweep=sweep), r, world, zlo, zhi, 100)
         sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
         slabs.append(sl)
     S.run_loopback(slabs, steps)
