@@ -20,6 +20,10 @@
 #include "sweep_common.h"
 
 #define SL_NONE 0xFFFFFFFFu
+#ifndef SL_WBUF
+#define SL_WBUF 8 // mask words buffered per lane before they are stored (2 KiB per wave);
+                  // measured: density 1.17 ms with 8, 1.26 ms with 16 (one resident wave fewer)
+#endif
 #ifndef SL_PV8
 #define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
@@ -122,8 +126,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask(DevParams P, SweepA
 template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
+    // Finished mask words wait here ([slot][lane]: conflict-free) until a lane has
+    // SL_WBUF of them, then leave as 16-byte stores: single-word stores to 64
+    // different streams made every word a partial-line write (measured 2.0 GB of
+    // WRITE_SIZE per launch for 0.28 GB of masks).
+    __shared__ uint32_t wbufAll[SW_WAVES][SL_WBUF * SPH_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
+    uint32_t *wbuf = wbufAll[w] + lane;
     const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
@@ -154,6 +164,30 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
     if (lane < SW_UNROLL) stage[SW_CAP + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
     const float4 *const sent = stage + SW_CAP;
     float rho = 0.f;
+    int pend = 0; // words of this lane waiting in wbuf
+    // write this lane's pending words (4 at a time) and empty its buffer
+    auto flush_words = [&]() {
+#pragma unroll
+        for (int q = 0; q < SL_WBUF; q += 4) {
+            if (q < pend) {
+                uint4 v;
+                v.x = wbuf[(q + 0) * SPH_WAVE];
+                v.y = wbuf[(q + 1) * SPH_WAVE];
+                v.z = wbuf[(q + 2) * SPH_WAVE];
+                v.w = wbuf[(q + 3) * SPH_WAVE];
+                uint32_t *dst = A.maskPool + woff + q;
+                if (q + 4 <= pend) {
+                    *reinterpret_cast<uint4 *>(dst) = v; // global_store_dwordx4 (dword aligned)
+                } else {
+                    dst[0] = v.x;
+                    if (q + 1 < pend) dst[1] = v.y;
+                    if (q + 2 < pend) dst[2] = v.z;
+                }
+            }
+        }
+        woff += (uint32_t)pend;
+        pend = 0;
+    };
     const int rowId = c.y + c.z * P.D;
     unsigned long long todo = __ballot(valid);
     while (todo) {
@@ -226,19 +260,21 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
                 for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
                 if (((k + SW_UNROLL) & 31) == 0) { // a whole word is complete (wave-uniform)
                     const int widx = k >> 5;
-                    if (ok && widx < nwords) A.maskPool[woff + widx] = m;
+                    if (ok && widx < nwords) wbuf[pend++ * SPH_WAVE] = m;
                     m = 0;
+                    if (__ballot(pend >= SL_WBUF)) flush_words();
                 }
             }
             if ((k & 31) != 0) { // last, partial word
                 const int widx = k >> 5;
-                if (ok && widx < nwords) A.maskPool[woff + widx] = m;
+                if (ok && widx < nwords) wbuf[pend++ * SPH_WAVE] = m;
+                if (__ballot(pend >= SL_WBUF)) flush_words();
             }
-            if (ok) woff += (uint32_t)nwords;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (ok) flush_words();
     if (valid) {
         rho = fmaxf(rho, SPH_EPS_F);
         A.vel4[i].w = rho;
