@@ -172,7 +172,7 @@ def main():
         pairs = kt.pair_tests / steps if kt.pair_tests else None
         achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
         roof = {"bound": "hbm", "kernel": {"lds": "k_density_lds", "direct": "k_density_direct",
-                                                   "list": "k_density_mask"}[args.sweep] + " (computeDensity)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "list": "k_density_mask_lds"}[args.sweep] + " (computeDensity)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": dens_s * 1e6,
                 "algorithmic_bytes_per_launch": DENSITY_BYTES_PER_PARTICLE * n_local,

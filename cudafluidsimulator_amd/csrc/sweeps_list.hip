@@ -20,6 +20,9 @@
 #include "sweep_common.h"
 
 #define SL_NONE 0xFFFFFFFFu
+#ifndef SL_VCONST
+#define SL_VCONST 0
+#endif
 #ifndef SL_WBUF
 #define SL_WBUF 8 // mask words buffered per lane before they are stored (2 KiB per wave);
                   // measured: density 1.17 ms with 8, 1.26 ms with 16 (one resident wave fewer)
@@ -164,6 +167,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
     if (lane < SW_UNROLL) stage[SW_CAP + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
     const float4 *const sent = stage + SW_CAP;
     float rho = 0.f;
+#if SL_VCONST
+    float h2v = P.h2, dcv = P.dcoef, cut2v = P.cut2;
+    asm volatile("" : "+v"(h2v), "+v"(dcv), "+v"(cut2v));
+#endif
     int pend = 0; // words of this lane waiting in wbuf
     // write this lane's pending words (4 at a time) and empty its buffer
     auto flush_words = [&]() {
@@ -222,22 +229,15 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
             const float4 *gcur = A.pos4 + (nonempty ? jsr : 0);
             uint32_t m = 0;
             int k = 0;
-            for (; __ballot(k < len); k += SW_UNROLL) {
-                float4 pj[SW_UNROLL];
-                if (staged) {
-#pragma unroll
-                    for (int u = 0; u < SW_UNROLL; ++u) {
-                        const float4 *p = (k + u < len) ? cur + k : sent;
-                        pj[u] = p[u];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < SW_UNROLL; ++u) {
-                        const bool in = k + u < len;
-                        pj[u] = gcur[in ? k + u : 0];
-                        pj[u].x = in ? pj[u].x : 1e18f; // out of range: fails every radius test
-                    }
-                }
+            // four candidates of one trip: density terms, hit bits, word hand-over
+            auto trip = [&](const float4 (&pj)[SW_UNROLL]) {
+#if SL_VCONST
+                // VALU ops with an SGPR source issue at half rate on gfx950
+                // (scripts/microbench/valu_rate.hip): keep the constants in VGPRs
+                const float h2 = h2v, dcoef = dcv, cut2 = cut2v;
+#else
+                const float h2 = P.h2, dcoef = P.dcoef, cut2 = P.cut2;
+#endif
 #pragma unroll
                 for (int u = 0; u < SW_UNROLL; ++u) {
                     float dx = pi.x - pj[u].x;
@@ -246,15 +246,15 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
                     float dist2;
                     if (FAST) {
                         dist2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        const float diff = fmaxf(P.h2 - dist2, 0.f);
-                        rho = __builtin_fmaf((SPH_MASS * P.dcoef) * (diff * diff), diff, rho);
+                        const float diff = fmaxf(h2 - dist2, 0.f);
+                        rho = __builtin_fmaf((SPH_MASS * dcoef) * (diff * diff), diff, rho);
                     } else {
                         dist2 = dx * dx + dy * dy + dz * dz;
-                        const float diff = fmaxf(P.h2 - dist2, 0.f);
-                        rho += SPH_MASS * (P.dcoef * diff * diff * diff);
+                        const float diff = fmaxf(h2 - dist2, 0.f);
+                        rho += SPH_MASS * (dcoef * diff * diff * diff);
                     }
                     const uint32_t bit = 1u << ((k + u) & 31); // wave-uniform
-                    m |= !(dist2 > P.cut2) ? bit : 0u;
+                    m |= !(dist2 > cut2) ? bit : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
@@ -263,6 +263,30 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
                     if (ok && widx < nwords) wbuf[pend++ * SPH_WAVE] = m;
                     m = 0;
                     if (__ballot(pend >= SL_WBUF)) flush_words();
+                }
+            };
+            // (two copies of the loop rather than one with a select in it: joining
+            // the LDS and the global candidates cost 20 register moves per trip)
+            if (staged) {
+                for (; __ballot(k < len); k += SW_UNROLL) {
+                    float4 pj[SW_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) {
+                        const float4 *p = (k + u < len) ? cur + k : sent;
+                        pj[u] = p[u];
+                    }
+                    trip(pj);
+                }
+            } else {
+                for (; __ballot(k < len); k += SW_UNROLL) {
+                    float4 pj[SW_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) {
+                        const bool in = k + u < len;
+                        pj[u] = gcur[in ? k + u : 0];
+                        pj[u].x = in ? pj[u].x : 1e18f; // out of range: fails every radius test
+                    }
+                    trip(pj);
                 }
             }
             if ((k & 31) != 0) { // last, partial word

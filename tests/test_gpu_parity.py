@@ -215,6 +215,36 @@ def test_fast_math_mode_within_north_star_tolerance():
     sim.close()
 
 
+@pytest.mark.parametrize("sweep", SWEEPS)
+def test_non_default_settings(sweep):
+    """Nothing is hard-wired to the reference's 100^3 grid: a 6.4-unit box with
+    h = 0.2 (32 cells per axis), a larger time step, 3001 particles."""
+    import ctypes as C
+    n = 3001
+    rng = np.random.default_rng(3)
+    s = sph.default_settings(n, False)
+    s.h = 0.2
+    s.boxDim = 6.4
+    s.numCellsPerDim = 32
+    s.timestep = 0.004
+    h = np.float32(s.h)
+    s.v_kernel_coeff = float(np.float32(45.0) / (np.float32(3.14159265) * np.float32(float(h) ** 6)))
+    s.d_kernel_coeff = float(np.float32(315.0) / (np.float32(64.0) * np.float32(3.14159265) * np.float32(float(h) ** 9)))
+    pos = rng.uniform(0.3, 6.1, (n, 3)).astype(np.float32)
+    vel = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    sim = sph.Simulator(s, sweep=sweep)
+    sim.upload_state(pos, vel)
+    ref = O.OracleSim(n, False)
+    C.memmove(C.byref(ref.settings), C.byref(s), C.sizeof(s))
+    ref.close()
+    ref._h = O.lib().oracle_sim_create(C.byref(ref.settings))
+    ref.upload(pos, vel)
+    for k in range(6):
+        sim.simulate(); ref.step()
+    compare_state(sim, ref, "custom settings")
+    sim.close()
+
+
 def test_list_sweep_pool_exhaustion_falls_back(monkeypatch):
     """A mask pool that is too small must only cost speed: waves that find it
     exhausted mark their particles and the force sweep tests every candidate."""
