@@ -116,7 +116,11 @@ struct WalkStamps {
 //    read while a global_load_lds is outstanding;
 //  * staging three runs per round trip (3 sub-buffers): staging stamps fell from
 //    32k to 20k cycles per wave but the extra registers cost a wave per SIMD and
-//    the sweeps got slower (density 1.02 ms, force 2.62 ms vs 0.98 / 2.40).
+//    the sweeps got slower (density 1.02 ms, force 2.62 ms vs 0.98 / 2.40);
+//  * a per-CELL table of the nine runs (72 MB, [run][cell]) read with 9 loads per
+//    particle instead of 27 gathers from the 8 MB cell table: slower (density
+//    1.11 -> 1.13 ms, force 1.57 -> 1.67 ms) -- the small table stays in L2, the
+//    big one does not.
 #define SW_SENTINEL SW_CAP // index of the far-away point inside the stage slice
 
 template <class Visitor>
