@@ -94,8 +94,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SPH_BENCH_SINGLE_DEVICE"):
+            # rehearsal of the multi-rank path on a one-GPU box: every rank uses
+            # cuda:0 and messages bounce through the host over gloo (never a result)
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N>1 must be launched through torch.distributed.run")
@@ -197,7 +204,9 @@ def main():
                                    + ("strict fp32 (bit-identical to the CPU oracle)" if args.math == "strict"
                                       else "FAST fp32 math (FMA, approximate rcp/rsq; 1e-5 tolerance mode)"),
                        "sweep": args.sweep,
-                       "parallelism": "single domain" if world == 1 else f"z-slabs x{world} + RCCL halo"},
+                       "parallelism": "single domain" if world == 1 else
+                       (f"z-slabs x{world} + RCCL halo" if not os.environ.get("SPH_BENCH_SINGLE_DEVICE")
+                        else f"REHEARSAL: z-slabs x{world} on ONE GPU, gloo via host")},
             "roofline": roof,
             "kernel_ms_per_step": {"hash": kt.hash / steps * 1e3, "sort": kt.sort / steps * 1e3,
                                    "gather_cells": kt.gather / steps * 1e3,
@@ -214,13 +223,13 @@ def main():
                                 "note": "SPH_MATH_FAST (FMA + approximate rcp/rsq): not bit-exact; max relative "
                                         "position error 8.1e-7 after 100 steps of -n 8192 -i grid vs the oracle "
                                         "(north-star tolerance 1e-5; tests/test_gpu_parity.py). Not `value`."}
-        tr = load_traffic(result["n_total"], args)
+        tr = load_traffic(result["n_total"], args) if world == 1 else None
         if tr:
             roof["traffic"] = tr["bytes_per_launch"]
             roof["traffic_source"] = tr["source"]
         if "stamps" in result:
             out["debug_stamps"] = result["stamps"]
-        if args.cpu_steps > 0:
+        if args.cpu_steps > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_particles or n, random_init, args.cpu_steps)
         print(json.dumps(out), flush=True)
 

@@ -267,8 +267,11 @@ class DistTransport:
     CUDA tensors, 'gloo' for CPU tensors.  Chain topology: rank r talks to r-1
     and r+1 only; no collective is needed on the data path."""
 
-    def __init__(self, dist, rank, world, device, group=None):
+    def __init__(self, dist, rank, world, device, group=None, via_cpu=False):
         self.dist, self.rank, self.world, self.device, self.group = dist, rank, world, device, group
+        # via_cpu: bounce every message through host memory (gloo has no CUDA
+        # point-to-point).  Only for rehearsing the multi-rank path on ONE GPU.
+        self.via_cpu = via_cpu
 
     def exchange_counts(self, to_dn, to_up):
         dist = self.dist
@@ -277,8 +280,9 @@ class DistTransport:
             if payload is None:
                 continue
             peer = self.rank + d
-            snd = torch.tensor(payload, dtype=torch.int64, device=self.device)
-            rcv = torch.zeros(len(payload), dtype=torch.int64, device=self.device)
+            cdev = "cpu" if self.via_cpu else self.device
+            snd = torch.tensor(payload, dtype=torch.int64, device=cdev)
+            rcv = torch.zeros(len(payload), dtype=torch.int64, device=cdev)
             bufs[d] = (snd, rcv)
             ops.append(dist.P2POp(dist.isend, snd, peer, group=self.group))
             ops.append(dist.P2POp(dist.irecv, rcv, peer, group=self.group))
@@ -290,14 +294,20 @@ class DistTransport:
 
     def exchange(self, sends, recvs):
         dist = self.dist
-        ops = []
+        ops, landing = [], []
         for d, x in _nonempty(sends):
-            ops.append(dist.P2POp(dist.isend, x, self.rank + d, group=self.group))
+            ops.append(dist.P2POp(dist.isend, x.cpu() if self.via_cpu else x, self.rank + d,
+                                  group=self.group))
         for d, x in _nonempty(recvs):
-            ops.append(dist.P2POp(dist.irecv, x, self.rank + d, group=self.group))
+            buf = torch.empty(x.shape, dtype=x.dtype) if self.via_cpu else x
+            landing.append((x, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, self.rank + d, group=self.group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if self.via_cpu:
+            for x, buf in landing:
+                x.copy_(buf)
 
 
 def step_distributed(slab, tr):
@@ -396,7 +406,7 @@ def run_slab_bench(args, dist, rank, world, local_rank):
     backend = HipSlabBackend(settings, cap, device=local_rank, sweep=args.sweep,
                              flags=_lib.SPH_FLAG_COUNT_PAIRS)
     slab = Slab(backend, rank, world, zlo, zhi, D)
-    tr = DistTransport(dist, rank, world, backend.device)
+    tr = DistTransport(dist, rank, world, backend.device, via_cpu=dist.get_backend() == "gloo")
     host = torch.empty((cap, 4), dtype=torch.float32).pin_memory()
 
     def reload():
