@@ -215,18 +215,19 @@ int alloc_device(sph_handle *h) {
     HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
     memset(h->hostPos, 0, posCap * 3 * sizeof(float));
     if (h->opt.sweep == SPH_SWEEP_LIST) {
-        // 64 mask words (2048 candidates) per particle slot; measured need at
-        // n = 4,194,304 random: 16 words early, 37 at step 100.  A wave that finds
-        // the pool exhausted falls back to testing (sweeps_list.hip).
-        unsigned long long words = (unsigned long long)cap * 64ull;
+        // 128 dwords per particle slot = room for 64 (first candidate, mask) pairs,
+        // i.e. 2048 candidates; the worst-case reservation measured at n = 4,194,304
+        // random is 32 dwords early and 74 at step 100.  A wave that finds the pool
+        // exhausted falls back to testing (sweeps_list.hip).
+        unsigned long long words = (unsigned long long)cap * 128ull;
         if (words < (1ull << 22)) words = 1ull << 22;
         if (const char *e = getenv("SPH_MASK_POOL_WORDS")) words = strtoull(e, nullptr, 10);
         if (words > 0xFFFFFFF0ull) words = 0xFFFFFFF0ull; // offsets are 32-bit
         h->maskCapacity = words;
         HIPCHK(h, hipMalloc(&h->maskPool, (size_t)(words ? words : 1) * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->pv8, cap * 2 * sizeof(float4)));
-        HIPCHK(h, hipMalloc(&h->maskOff, cap * sizeof(uint32_t)));
-        HIPCHK(h, hipMemset(h->maskOff, 0xFF, cap * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->maskOff, cap * 2 * sizeof(uint32_t))); // {first dword, dwords}
+        HIPCHK(h, hipMemset(h->maskOff, 0xFF, cap * 2 * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->maskCursor, sizeof(unsigned long long)));
         HIPCHK(h, hipMemset(h->maskCursor, 0, sizeof(unsigned long long)));
     }

@@ -87,7 +87,7 @@ struct SweepArgs {
     int n_all;
     // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
     uint32_t *maskPool;               // pool of 32-candidate mask words
-    uint32_t *maskOff;                // per sorted particle: first word, or ~0u
+    uint32_t *maskOff;                // per sorted particle: {first dword or ~0u, dwords}
     unsigned long long *maskCursor;   // words handed out this step
     unsigned long long maskCapacity;  // pool size in words
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams

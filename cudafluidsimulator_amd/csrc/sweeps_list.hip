@@ -20,6 +20,11 @@
 #include "sweep_common.h"
 
 #define SL_NONE 0xFFFFFFFFu
+#ifndef SL_WINDOW
+#define SL_WINDOW 128 // records around the wave's own particles cached in LDS by the force sweep
+                      // (0 = off).  Measured: 1.60 -> 1.49 ms; 256 records or three rows
+                      // (12 KiB per wave) lose more to occupancy than they save.
+#endif
 #ifndef SL_VCONST
 #define SL_VCONST 0
 #endif
@@ -31,9 +36,6 @@
 #define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
 #endif
-#ifndef SL_DIRECT_MASKS
-#define SL_DIRECT_MASKS 0 // 1: one-thread-per-particle mask builder (A/B and fallback study)
-#endif
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -42,78 +44,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
         if (lane >= off) v += t;
     }
     return v;
-}
-
-// ---------------------------------------------------------------------------
-// density + hit masks.  One thread per particle, candidates straight from
-// global memory (neighbouring lanes read the same few cache lines).
-// ---------------------------------------------------------------------------
-template <bool FAST>
-__global__ __launch_bounds__(SW_THREADS) void k_density_mask(DevParams P, SweepArgs A) {
-    const int lane = threadIdx.x & 63;
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    const bool valid = i < A.i_end;
-    float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
-    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
-    int js[9], je[9];
-    load_runs(P, A.cellRange, c, valid, js, je);
-
-    // carve this wave's slice of the mask pool
-    uint32_t words = 0, pairs = 0;
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        words += (uint32_t)(je[r] - js[r] + 31) >> 5;
-        pairs += (uint32_t)(je[r] - js[r]);
-    }
-    const uint32_t incl = wave_incl_scan_u32(words, lane);
-    const uint32_t total = __shfl(incl, 63);
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(A.maskCursor, (unsigned long long)total);
-    base = (unsigned long long)__shfl((unsigned)(base >> 32), 0) << 32 |
-           (unsigned long long)__shfl((unsigned)base, 0);
-    const bool ok = base + total <= A.maskCapacity; // wave-uniform
-    uint32_t off = ok ? (uint32_t)base + (incl - words) : SL_NONE;
-    if (valid) A.maskOff[i] = off;
-    if (A.pairCounter) {
-        uint32_t s = wave_sum_u32(pairs);
-        if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
-    }
-
-    float rho = 0.f;
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int len = je[r] - js[r];
-        for (int k0 = 0; k0 < len; k0 += 32) {
-            uint32_t m = 0;
-            const int kn = min(32, len - k0);
-            const float4 *cand = A.pos4 + js[r] + k0;
-#pragma unroll 4
-            for (int b = 0; b < kn; ++b) {
-                const float4 pj = cand[b];
-                float dx = pi.x - pj.x;
-                float dy = pi.y - pj.y;
-                float dz = pi.z - pj.z;
-                float dist2;
-                if (FAST) {
-                    dist2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    const float diff = fmaxf(P.h2 - dist2, 0.f);
-                    rho = __builtin_fmaf((SPH_MASS * P.dcoef) * (diff * diff), diff, rho);
-                } else {
-                    dist2 = dx * dx + dy * dy + dz * dz;
-                    const float diff = fmaxf(P.h2 - dist2, 0.f);
-                    rho += SPH_MASS * (P.dcoef * diff * diff * diff);
-                }
-                // a "hit" is any candidate for which a force term can be non-zero
-                m |= (!(dist2 > P.cut2) ? 1u : 0u) << b;
-            }
-            if (ok) A.maskPool[off++] = m;
-        }
-    }
-    if (valid) {
-        rho = fmaxf(rho, SPH_EPS_F);
-        A.vel4[i].w = rho;
-        A.pv8[2 * (size_t)i + 1].w = rho;
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -144,10 +74,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
     int js[9], je[9];
     load_runs(P, A.cellRange, c, valid, js, je);
 
+    // pool space for the worst case: one (first candidate, mask) pair per 32 candidates
     uint32_t words = 0, pairs = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-        words += (uint32_t)(je[r] - js[r] + 31) >> 5;
+        words += 2u * ((uint32_t)(je[r] - js[r] + 31) >> 5);
         pairs += (uint32_t)(je[r] - js[r]);
     }
     const uint32_t incl = wave_incl_scan_u32(words, lane);
@@ -158,7 +89,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
            (unsigned long long)__shfl((unsigned)base, 0);
     const bool ok = base + total <= A.maskCapacity; // wave-uniform
     uint32_t woff = ok ? (uint32_t)base + (incl - words) : SL_NONE;
-    if (valid) A.maskOff[i] = woff;
+    const uint32_t woff0 = woff;
     if (A.pairCounter) {
         uint32_t s = wave_sum_u32(pairs);
         if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
@@ -218,7 +149,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
             const int u0 = __builtin_amdgcn_readlane(jsr, lo);
             const int u1 = __builtin_amdgcn_readlane(jer, hi);
             const int len = nonempty ? jer - jsr : 0;          // this lane's candidates
-            const int nwords = (len + 31) >> 5;                // and mask words for this run
+
             const bool staged = (u1 - u0) <= SW_CAP;           // wave-uniform
             if (staged) {
                 for (int k = lane; k < u1 - u0; k += SPH_WAVE) stage[k] = A.pos4[u0 + k];
@@ -259,8 +190,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 #pragma unroll
                 for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
                 if (((k + SW_UNROLL) & 31) == 0) { // a whole word is complete (wave-uniform)
-                    const int widx = k >> 5;
-                    if (ok && widx < nwords) wbuf[pend++ * SPH_WAVE] = m;
+                    if (ok && m != 0) { // empty words are not stored
+                        wbuf[pend++ * SPH_WAVE] = (uint32_t)(jsr + (k & ~31));
+                        wbuf[pend++ * SPH_WAVE] = m;
+                    }
                     m = 0;
                     if (__ballot(pend >= SL_WBUF)) flush_words();
                 }
@@ -290,8 +223,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
                 }
             }
             if ((k & 31) != 0) { // last, partial word
-                const int widx = k >> 5;
-                if (ok && widx < nwords) wbuf[pend++ * SPH_WAVE] = m;
+                if (ok && m != 0) {
+                    wbuf[pend++ * SPH_WAVE] = (uint32_t)(jsr + (k & ~31));
+                    wbuf[pend++ * SPH_WAVE] = m;
+                }
                 if (__ballot(pend >= SL_WBUF)) flush_words();
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -299,6 +234,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
         }
     }
     if (ok) flush_words();
+    if (valid) { // where this particle's pairs start and how many dwords they take
+        A.maskOff[2 * (size_t)i] = woff0;
+        A.maskOff[2 * (size_t)i + 1] = ok ? woff - woff0 : 0u;
+    }
     if (valid) {
         rho = fmaxf(rho, SPH_EPS_F);
         A.vel4[i].w = rho;
@@ -309,62 +248,71 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 // ---------------------------------------------------------------------------
 // force + integrate over the recorded hits
 // ---------------------------------------------------------------------------
+#ifndef SL_K2_WAVES
+#define SL_K2_WAVES 0 // >0: ask for that many resident waves per SIMD (caps the VGPR budget)
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(SW_THREADS) void k_force_list(DevParams P, SweepArgs A) {
+__global__
+#if SL_K2_WAVES
+__launch_bounds__(SW_THREADS, SL_K2_WAVES)
+#else
+__launch_bounds__(SW_THREADS)
+#endif
+void k_force_list(DevParams P, SweepArgs A) {
     const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     const int iSafe = valid ? i : A.i_begin;
     float4 pi = A.pos4[iSafe];
     const float4 vi = A.vel4[iSafe];
     const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
-    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
-    int js[9], je[9];
-    load_runs(P, A.cellRange, c, valid, js, je);
-    const uint32_t off = valid ? A.maskOff[i] : 0u;
+    // this particle's stream of (first candidate, 32-bit hit mask) pairs
+    const uint32_t off = valid ? A.maskOff[2 * (size_t)i] : 0u;
+    const int total = valid ? (int)A.maskOff[2 * (size_t)i + 1] : 0; // dwords
     ForceAcc F = {0.f, 0.f, 0.f};
 
-    if (__ballot(valid && off == SL_NONE)) {
-        // pool was exhausted for this wave: test every candidate (check-path code)
-#pragma unroll
-        for (int r = 0; r < 9; ++r)
-            for (int j = js[r]; j < je[r]; ++j) {
-                if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
-                else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
-            }
-    } else {
-        // word index -> first candidate of that word: 32*wi + adj[run(wi)], where
-        // cw[r] = words before run r.  (Static indexing only: nothing spills.)
-        int cw[10], adj[9];
-        cw[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            cw[r + 1] = cw[r] + ((je[r] - js[r] + 31) >> 5);
-            adj[r] = js[r] - 32 * cw[r];
-        }
-        const int total = cw[9];
-        auto base_of = [&](int wi) {
-            int a = adj[0];
-#pragma unroll
-            for (int r = 1; r < 9; ++r) a = (wi >= cw[r]) ? adj[r] : a;
-            return 32 * wi + a;
-        };
-        const uint32_t *stream = A.maskPool + off;
-        // Bit cursor.  m: bits of the current word; mn: the next word, already in
-        // flight.  pop() returns the next hit's sorted index, or the particle itself
-        // once the stream is exhausted (dist = 0 gates every term: exact no-op).
+#if SL_WINDOW
+    // LDS copy of the records around the wave's own particles.  The kernel is bound
+    // by the texture addresser's gather rate (PMC: TA busy 89 %), and ~40 % of all
+    // hits are neighbours in the particle's own grid row, i.e. within a few dozen
+    // slots of the wave's 64 particles in the sorted stream: those are served by
+    // ds_read_b128 instead of a 64-address global gather.
+    __shared__ float4 winAll[SW_WAVES][2 * SL_WINDOW];
+    float4 *win = winAll[threadIdx.x >> 6];
+    const int tile0 = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + (threadIdx.x & ~63);
+    const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
+    const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
+    {
+        const int lane = threadIdx.x & 63;
+        for (int k = lane; k < 2 * wlen; k += SPH_WAVE) win[k] = A.pv8[2 * (size_t)w0 + k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
+
+    // A wave that found the mask pool exhausted has no stream: its particles are
+    // handled by k_force_fallback (kept out of this kernel: its 27 table reads and
+    // run arrays would cost two resident waves per SIMD here).
+    if (__ballot(valid && off == SL_NONE)) return;
+    {
+        const uint2 *stream = reinterpret_cast<const uint2 *>(A.maskPool + off);
+        const int npairs = total >> 1;
+        // Bit cursor.  (jb, m): first candidate and remaining bits of the current
+        // pair; (jbn, mn): the next pair, already in flight.  pop() returns the next
+        // hit's sorted index, or the particle itself once the stream is exhausted
+        // (dist = 0 gates every term: exact no-op).
         int wi = 0;
         uint32_t m = 0, mn = 0;
         int jb = 0, jbn = 0;
         bool live = true;
-        if (wi < total) { mn = stream[wi]; jbn = base_of(wi); ++wi; }
+        if (wi < npairs) { const uint2 t = stream[wi]; jbn = (int)t.x; mn = t.y; ++wi; }
         auto pop = [&]() -> int {
-            if (m == 0) { // take the prefetched word, start fetching the one after
+            if (m == 0) { // take the prefetched pair, start fetching the one after
                 m = mn;
                 jb = jbn;
                 mn = 0;
-                if (wi < total) { mn = stream[wi]; jbn = base_of(wi); ++wi; }
+                if (wi < npairs) { const uint2 t = stream[wi]; jbn = (int)t.x; mn = t.y; ++wi; }
             }
-            live = (m | mn) != 0 || wi < total;
+            live = (m | mn) != 0;
             const bool has = m != 0;
             const int b = has ? __builtin_ctz(m) : 0;
             m &= m - 1u; // (0 stays 0)
@@ -376,29 +324,44 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_list(DevParams P, SweepArg
         };
         // Two gathers are always in flight while a pair body is evaluated: the
         // loop is unrolled by two so the pipeline registers never move.
-#if SL_PV8
-#define SL_POS(j) A.pv8[2 * (size_t)(j)]
-#define SL_VEL(j) A.pv8[2 * (size_t)(j) + 1]
+#if SL_WINDOW
+        // fetch: issue the global gather only for lanes whose hit is outside the
+        // window (fewer active lanes = fewer addresses for the TA); the LDS copy is
+        // read when the hit is consumed.
+#define SL_FETCH(j, p, v)                                                      \
+    if ((unsigned)((j)-w0) >= (unsigned)wlen) {                                \
+        p = A.pv8[2 * (size_t)(j)];                                            \
+        v = A.pv8[2 * (size_t)(j) + 1];                                        \
+    }
+#define SL_USE(j, p, v)                                                        \
+    if ((unsigned)((j)-w0) < (unsigned)wlen) {                                 \
+        p = win[2 * ((j)-w0)];                                                 \
+        v = win[2 * ((j)-w0) + 1];                                             \
+    }                                                                          \
+    body(p, v);
 #else
-#define SL_POS(j) A.pos4[j]
-#define SL_VEL(j) A.vel4[j]
+#define SL_FETCH(j, p, v)                                                      \
+    p = A.pv8[2 * (size_t)(j)];                                                \
+    v = A.pv8[2 * (size_t)(j) + 1];
+#define SL_USE(j, p, v) body(p, v);
 #endif
+        float4 p0 = make_float4(0, 0, 0, 0), v0 = p0, p1 = p0, v1 = p0;
         int j0 = pop();
-        float4 p0 = SL_POS(j0), v0 = SL_VEL(j0);
+        SL_FETCH(j0, p0, v0)
         int j1 = pop();
-        float4 p1 = SL_POS(j1), v1 = SL_VEL(j1);
+        SL_FETCH(j1, p1, v1)
         for (;;) {
-            body(p0, v0);
+            SL_USE(j0, p0, v0)
             j0 = pop();
-            if (!__ballot(live)) { body(p1, v1); p0 = SL_POS(j0); v0 = SL_VEL(j0); body(p0, v0); break; }
-            p0 = SL_POS(j0);
-            v0 = SL_VEL(j0);
-            body(p1, v1);
+            if (!__ballot(live)) { SL_USE(j1, p1, v1) SL_FETCH(j0, p0, v0) SL_USE(j0, p0, v0) break; }
+            SL_FETCH(j0, p0, v0)
+            SL_USE(j1, p1, v1)
             j1 = pop();
-            if (!__ballot(live)) { body(p0, v0); p1 = SL_POS(j1); v1 = SL_VEL(j1); body(p1, v1); break; }
-            p1 = SL_POS(j1);
-            v1 = SL_VEL(j1);
+            if (!__ballot(live)) { SL_USE(j0, p0, v0) SL_FETCH(j1, p1, v1) SL_USE(j1, p1, v1) break; }
+            SL_FETCH(j1, p1, v1)
         }
+#undef SL_FETCH
+#undef SL_USE
     }
     if (valid) {
         float vx = vi.x, vy = vi.y, vz = vi.z;
@@ -411,13 +374,37 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-#if SL_DIRECT_MASKS
-    if (mathMode == 1) k_density_mask<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
-    else k_density_mask<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
-#else
     if (mathMode == 1) k_density_mask_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
     else k_density_mask_lds<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
-#endif
+}
+
+// Particles whose wave found the mask pool exhausted in the density sweep: test
+// every candidate, like the check path.  Launched after k_force_list every step;
+// waves with nothing to do leave after one load.
+template <bool FAST>
+__global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, SweepArgs A) {
+    const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = i < A.i_end && A.maskOff[2 * (size_t)i] == SL_NONE;
+    if (!__ballot(mine)) return;
+    const int iSafe = mine ? i : A.i_begin;
+    float4 pi = A.pos4[iSafe];
+    const float4 vi = A.vel4[iSafe];
+    const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
+    int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
+    int js[9], je[9];
+    load_runs(P, A.cellRange, c, mine, js, je);
+    ForceAcc F = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+        for (int j = js[r]; j < je[r]; ++j) {
+            if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+            else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+        }
+    if (mine) {
+        float vx = vi.x, vy = vi.y, vz = vi.z;
+        integrate_particle(P, pi, vx, vy, vz, F, vi.w);
+        store_particle(A, i, pi, vx, vy, vz, vi.w, F);
+    }
 }
 
 // Slab path: rho (and velocity) of HALO particles arrive in vel4 through exchange
@@ -435,6 +422,11 @@ void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode,
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
     const int halo = A.i_begin + (A.n_all - A.i_end);
     if (halo > 0) k_patch_pv8<<<(halo + 255) / 256, 256, 0, s>>>(A.vel4, A.pv8, A.i_begin, A.i_end, A.n_all);
-    if (mathMode == 1) k_force_list<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
-    else k_force_list<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    if (mathMode == 1) {
+        k_force_list<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_fallback<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    } else {
+        k_force_list<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_fallback<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    }
 }
