@@ -22,11 +22,12 @@
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 
 // Lanes of this wave whose digit equals mine (among valid lanes).
+template <int BITS>
 __device__ __forceinline__ unsigned long long match_digit(uint32_t digit,
                                                           bool valid) {
     unsigned long long m = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BITS; ++b) {
         bool bit = (digit >> b) & 1u;
         unsigned long long v = __ballot(valid && bit);
         m &= bit ? v : ~v;
@@ -40,12 +41,17 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// BITS = 8 or 10 bits per pass: the 20-bit flattened cell key sorts in TWO 10-bit
+// passes (1024 digits, four per thread) instead of three 8-bit ones.
+template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
     int shift, int numBlocks) {
-    __shared__ uint32_t hist[256];
+    constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
+    __shared__ uint32_t hist[DIG];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    hist[t] = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) hist[t + q * RS_THREADS] = 0;
     __syncthreads();
     const long long base =
         (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_TILE + lane;
@@ -54,12 +60,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
         long long idx = base + r * SPH_WAVE;
         bool valid = idx < n;
         uint32_t key = valid ? keys[idx] : 0u;
-        uint32_t d = (key >> shift) & 255u;
-        unsigned long long m = match_digit(d, valid);
+        uint32_t d = (key >> shift) & (DIG - 1);
+        unsigned long long m = match_digit<BITS>(d, valid);
         if (valid && lanes_below(m) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(m));
     }
     __syncthreads();
-    blockHist[(size_t)t * numBlocks + blockIdx.x] = hist[t];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int d = t + q * RS_THREADS;
+        blockHist[(size_t)d * numBlocks + blockIdx.x] = hist[d];
+    }
 }
 
 // Block-wide inclusive scan of one value per thread (256 threads).
@@ -78,8 +88,8 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v,
     return tmp[t];
 }
 
-// grid = 256 workgroups (one per digit); exclusive scan of that digit's row of
-// tile counts, in place, and the digit's total.
+// grid = one workgroup per digit; exclusive scan of that digit's row of tile
+// counts, in place, and the digit's total.
 __global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(
     uint32_t *__restrict__ blockHist, uint32_t *__restrict__ digitTotal,
     int numBlocks) {
@@ -100,22 +110,36 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(
     }
 }
 
+template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
     uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut,
     const uint32_t *__restrict__ blockHist,
     const uint32_t *__restrict__ digitTotal, int n, int shift, int numBlocks) {
-    __shared__ uint32_t waveCount[RS_WAVES][256];
-    __shared__ uint32_t digitOff[256];
+    constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
+    __shared__ uint32_t waveCount[RS_WAVES][DIG];
+    __shared__ uint32_t digitOff[DIG];
     __shared__ uint32_t tmp[RS_THREADS];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 #pragma unroll
-    for (int q = 0; q < RS_WAVES; ++q) waveCount[q][t] = 0;
-    // global base of digit t for this tile = (sum of totals of smaller digits)
-    // + (count of digit t in earlier tiles)
-    uint32_t tot = digitTotal[t];
-    uint32_t incl = block_inclusive_scan_256(tot, tmp); // ends with a barrier
-    uint32_t myBase = (incl - tot) + blockHist[(size_t)t * numBlocks + blockIdx.x];
+    for (int q = 0; q < RS_WAVES; ++q)
+#pragma unroll
+        for (int e = 0; e < PER; ++e) waveCount[q][t * PER + e] = 0;
+    // thread t owns digits [t*PER, t*PER+PER).  Global base of a digit for this
+    // tile = (sum of totals of smaller digits) + (its count in earlier tiles).
+    uint32_t tot[PER], sum = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        tot[e] = digitTotal[t * PER + e];
+        sum += tot[e];
+    }
+    uint32_t run = block_inclusive_scan_256(sum, tmp) - sum; // ends with a barrier
+    uint32_t myBase[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        myBase[e] = run + blockHist[(size_t)(t * PER + e) * numBlocks + blockIdx.x];
+        run += tot[e];
+    }
 
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
     const long long base =
@@ -131,8 +155,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     for (int r = 0; r < RS_ITEMS; ++r) {
         long long idx = base + r * SPH_WAVE;
         bool valid = idx < n;
-        uint32_t d = (key[r] >> shift) & 255u;
-        unsigned long long m = match_digit(d, valid);
+        uint32_t d = (key[r] >> shift) & (DIG - 1);
+        unsigned long long m = match_digit<BITS>(d, valid);
         uint32_t below = lanes_below(m);
         uint32_t old = waveCount[w][d]; // every lane reads before the leader adds
         rank[r] = old + below;
@@ -140,20 +164,22 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {
-        uint32_t c0 = waveCount[0][t], c1 = waveCount[1][t], c2 = waveCount[2][t];
-        waveCount[0][t] = 0;
-        waveCount[1][t] = c0;
-        waveCount[2][t] = c0 + c1;
-        waveCount[3][t] = c0 + c1 + c2;
-        digitOff[t] = myBase;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int d = t * PER + e;
+        uint32_t c0 = waveCount[0][d], c1 = waveCount[1][d], c2 = waveCount[2][d];
+        waveCount[0][d] = 0;
+        waveCount[1][d] = c0;
+        waveCount[2][d] = c0 + c1;
+        waveCount[3][d] = c0 + c1 + c2;
+        digitOff[d] = myBase[e];
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         long long idx = base + r * SPH_WAVE;
         if (idx < n) {
-            uint32_t d = (key[r] >> shift) & 255u;
+            uint32_t d = (key[r] >> shift) & (DIG - 1);
             uint32_t dst = digitOff[d] + waveCount[w][d] + rank[r];
             keysOut[dst] = key[r];
             valsOut[dst] = val[r];
@@ -165,18 +191,28 @@ size_t sph_sort_workspace_blocks(int n) {
     return (size_t)((n + RS_TILE - 1) / RS_TILE);
 }
 
+template <int BITS>
+static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, int numBlocks,
+                       hipStream_t s) {
+    k_radix_hist<BITS><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
+                                                        numBlocks);
+    k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
+    k_radix_scatter<BITS><<<numBlocks, RS_THREADS, 0, s>>>(
+        ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist,
+        ws.digitTotal, n, shift, numBlocks);
+}
+
 int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s) {
     if (n <= 0) return 0;
     const int numBlocks = (n + RS_TILE - 1) / RS_TILE;
+    // fewest passes with 8- or 10-bit digits: <=8: 8 | <=10: 10 | <=16: 8+8 |
+    // <=20: 10+10 (the 100^3 grid) | <=24: 8+8+8 | <=30: 10+10+10 | else 8-bit passes
+    int digit = 8;
+    if ((bits > 8 && bits <= 10) || (bits > 16 && bits <= 20) || (bits > 24 && bits <= 30)) digit = 10;
     int cur = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
-        k_radix_hist<<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n,
-                                                      shift, numBlocks);
-        k_radix_rowscan<<<256, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal,
-                                                   numBlocks);
-        k_radix_scatter<<<numBlocks, RS_THREADS, 0, s>>>(
-            ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1],
-            ws.blockHist, ws.digitTotal, n, shift, numBlocks);
+    for (int shift = 0; shift < bits; shift += digit) {
+        if (digit == 10) radix_pass<10>(ws, cur, n, shift, numBlocks, s);
+        else radix_pass<8>(ws, cur, n, shift, numBlocks, s);
         cur ^= 1;
     }
     return cur;

@@ -207,9 +207,9 @@ int alloc_device(sph_handle *h) {
     h->ws.capacity = (int)cap;
     h->ws.maxBlocks = (int)sph_sort_workspace_blocks((int)cap);
     HIPCHK(h, hipMalloc(&h->ws.blockHist,
-                        (size_t)256 * (size_t)(h->ws.maxBlocks > 0 ? h->ws.maxBlocks : 1) *
+                        (size_t)1024 * (size_t)(h->ws.maxBlocks > 0 ? h->ws.maxBlocks : 1) *
                             sizeof(uint32_t)));
-    HIPCHK(h, hipMalloc(&h->ws.digitTotal, 256 * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->ws.digitTotal, 1024 * sizeof(uint32_t)));
     HIPCHK(h, hipMalloc(&h->cellRange, (size_t)h->P.numCells * sizeof(int2)));
     HIPCHK(h, hipMemset(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2)));
     HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
@@ -974,8 +974,8 @@ int sph_sort_check(int device, const uint32_t *keys, int n, int key_bits_, uint3
         ok = ok && hipMalloc(&ws.keys[b], (size_t)n * 4) == hipSuccess;
         ok = ok && hipMalloc(&ws.vals[b], (size_t)n * 4) == hipSuccess;
     }
-    ok = ok && hipMalloc(&ws.blockHist, 256 * nb * 4) == hipSuccess;
-    ok = ok && hipMalloc(&ws.digitTotal, 256 * 4) == hipSuccess;
+    ok = ok && hipMalloc(&ws.blockHist, 1024 * nb * 4) == hipSuccess;
+    ok = ok && hipMalloc(&ws.digitTotal, 1024 * 4) == hipSuccess;
     for (int b = 0; b < 2 && ok; ++b) {
         ok = ok && hipMemset(ws.keys[b], 0, (size_t)n * 4) == hipSuccess;
         ok = ok && hipMemset(ws.vals[b], 0, (size_t)n * 4) == hipSuccess;

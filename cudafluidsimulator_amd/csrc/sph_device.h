@@ -47,8 +47,8 @@ struct DevParams {
 struct SortWorkspace {
     uint32_t *keys[2];
     uint32_t *vals[2];
-    uint32_t *blockHist;  // [256][numBlocks], digit-major
-    uint32_t *digitTotal; // [256]
+    uint32_t *blockHist;  // [digits <= 1024][numBlocks], digit-major
+    uint32_t *digitTotal; // [digits]
     int capacity;         // elements
     int maxBlocks;
 };
