@@ -418,7 +418,8 @@ def run_slab_bench(args, dist, rank, world, local_rank):
         host[:len(p)].copy_(p, non_blocking=True)   # per-step position read-back (simulator.cu:479)
 
     reload()
-    for _ in range(args.warmup):
+    # at least one untimed step: the first P2P call builds the RCCL communicators
+    for _ in range(max(args.warmup, 1)):
         one_step()
     reload()
     backend.kernel_times(reset=True)
