@@ -20,6 +20,23 @@
 #include "sweep_common.h"
 
 #define SL_NONE 0xFFFFFFFFu
+
+// In-kernel phase stamps (diagnostic builds only: -DSW_STAMPS=1), as in sweeps.hip.
+#ifndef SW_STAMPS
+#define SW_STAMPS 0
+#endif
+#if SW_STAMPS
+__device__ __forceinline__ unsigned long long sl_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define SL_STAMP(var) unsigned long long var = sl_stamp()
+#else
+#define SL_STAMP(var)
+#endif
 #ifndef SL_WINDOW
 #define SL_WINDOW 128 // records around the wave's own particles cached in LDS by the force sweep
                       // (0 = off).  Measured: 1.60 -> 1.49 ms; 256 records or three rows
@@ -67,6 +84,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
     uint32_t *wbuf = wbufAll[w] + lane;
+    SL_STAMP(t0);
+#if SW_STAMPS
+    unsigned long long accStage = 0, accTest = 0;
+#endif
     const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
@@ -98,6 +119,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
     if (lane < SW_UNROLL) stage[SW_CAP + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
     const float4 *const sent = stage + SW_CAP;
     float rho = 0.f;
+#if SW_STAMPS
+    asm volatile("" ::"v"(js[0] + je[8] + (int)woff));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    SL_STAMP(t1);
 #if SL_VCONST
     float h2v = P.h2, dcv = P.dcoef, cut2v = P.cut2;
     asm volatile("" : "+v"(h2v), "+v"(dcv), "+v"(cut2v));
@@ -151,11 +177,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
             const int len = nonempty ? jer - jsr : 0;          // this lane's candidates
 
             const bool staged = (u1 - u0) <= SW_CAP;           // wave-uniform
+            SL_STAMP(tA);
             if (staged) {
                 for (int k = lane; k < u1 - u0; k += SPH_WAVE) stage[k] = A.pos4[u0 + k];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+#if SW_STAMPS
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
             }
+            SL_STAMP(tB);
             const float4 *cur = stage + (nonempty ? jsr - u0 : 0);
             const float4 *gcur = A.pos4 + (nonempty ? jsr : 0);
             uint32_t m = 0;
@@ -231,8 +262,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#if SW_STAMPS
+            {
+                SL_STAMP(tC);
+                accStage += tB - tA;
+                accTest += tC - tB;
+            }
+#endif
         }
     }
+    SL_STAMP(t2);
     if (ok) flush_words();
     if (valid) { // where this particle's pairs start and how many dwords they take
         A.maskOff[2 * (size_t)i] = woff0;
@@ -243,6 +282,20 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
         A.vel4[i].w = rho;
         A.pv8[2 * (size_t)i + 1].w = rho;
     }
+#if SW_STAMPS
+    {
+        SL_STAMP(t3);
+        if (lane == 0 && A.stampCounter) {
+            unsigned long long *S = A.stampCounter + 16 + (blockIdx.x & 255) * 16;
+            atomicAdd(S + 1, t1 - t0);   // prologue (pos, cell, 27 table reads, pool slice)
+            atomicAdd(S + 2, accStage);  // staging (global -> LDS) incl. waits
+            atomicAdd(S + 3, accTest);   // test loops incl. mask hand-over
+            atomicAdd(S + 4, t3 - t0);   // whole wave
+            atomicAdd(S + 5, 1ull);      // waves
+            atomicAdd(S + 13, t3 - t2);  // final flush + stores
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
