@@ -60,11 +60,24 @@ def cpu_baseline(n, random_init, steps):
     sim.step(steps)
     dt = time.perf_counter() - t0
     sim.close()
-    return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(),
-            "kind": "port",
-            "sample": f"first {steps} steps of -n {n} -i {'random' if random_init else 'grid'} "
-                      f"(of the 100-step run; later steps cost up to 4.7x more), "
-                      f"OpenMP oracle, {dt:.1f} s"}
+    out = {"value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(),
+           "kind": "port",
+           "sample": f"first {steps} steps of -n {n} -i {'random' if random_init else 'grid'} "
+                     f"(of the 100-step run; later steps cost up to 4.7x more), "
+                     f"OpenMP oracle, {dt:.1f} s"}
+    # the same oracle on ONE core (bounded: the first step only)
+    all_threads = O.num_threads()
+    O.set_num_threads(1)
+    sim = O.OracleSim(n, random_init)
+    sim.setup()
+    t0 = time.perf_counter()
+    sim.step(1)
+    dt1 = time.perf_counter() - t0
+    sim.close()
+    O.set_num_threads(all_threads)
+    out["single_thread"] = {"value": n / dt1, "unit": "particle-steps/s", "cores": 1,
+                            "sample": f"first step only, {dt1:.1f} s"}
+    return out
 
 
 def load_traffic(n, args):

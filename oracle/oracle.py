@@ -81,6 +81,7 @@ def lib():
     L.oracle_sim_last_pair_tests.argtypes = [C.c_void_p]
     L.oracle_sim_last_pair_tests.restype = C.c_uint64
     L.oracle_num_threads.restype = C.c_int
+    L.oracle_set_num_threads.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -236,3 +237,7 @@ class OracleSim:
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def set_num_threads(t):
+    lib().oracle_set_num_threads(int(t))

@@ -33,6 +33,14 @@
 #define O_BOX_MAX_Y (450)
 #define O_BOX_MIN_Y (150)
 
+void oracle_set_num_threads(int t) {
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -117,6 +117,7 @@ int oracle_sim_sorted(const OracleSim *sim, uint32_t *ids, uint32_t *keys,
                       float *pos_xyz, float *vel_xyz);
 uint64_t oracle_sim_last_pair_tests(const OracleSim *sim);
 int oracle_num_threads(void);
+void oracle_set_num_threads(int t); /* OpenMP threads for the sweeps (results do not change) */
 
 #ifdef __cplusplus
 }
