@@ -36,12 +36,14 @@ def parse():
     ap.add_argument("-n", "--particles", type=int, default=4194304,
                     help="BASELINE.json configs[2]: -n 4194304 -i random -m time")
     ap.add_argument("--init", choices=["random", "grid"], default="random")
-    ap.add_argument("--sweep", choices=["list", "lds", "direct"], default="list")
+    ap.add_argument("--sweep", choices=["list", "lds", "direct", "linked"], default="list")
     ap.add_argument("--math", choices=["strict", "fast"], default="strict",
                     help="strict: bit-identical to the oracle (default); fast: FMA + approximate "
                          "rcp/rsq, tolerance-checked")
     ap.add_argument("--mode", choices=["time", "free"], default="time",
                     help="time: simulateAndTime loop (-m time); free: simulate() loop")
+    ap.add_argument("--no-linked-leg", action="store_true",
+                    help="skip the secondary run of the reference's linked-list neighbour structure")
     ap.add_argument("--no-fast-leg", action="store_true",
                     help="skip the extra SPH_MATH_FAST measurement")
     ap.add_argument("--cpu-steps", type=int, default=12,
@@ -160,7 +162,26 @@ def main():
         if os.environ.get("SPH_STAMPS"):
             result["stamps"] = sim.debug_counters()
         sim.close()
-        if args.math == "strict" and args.sweep != "direct" and not args.no_fast_leg:
+        if args.sweep == "list" and args.math == "strict" and not args.no_linked_leg:
+            # secondary figure: the reference's own neighbour structure (per-cell
+            # linked lists, no sort) on this GPU, same K steps (not `value`)
+            lsim = sph.Simulator(s, sweep="linked", device=local_rank)
+            lsim.setup()
+            lt = sph.Times()
+            lsim.simulateAndTime(lt)
+            lsim.sync()
+            lsim.setup()
+            lsim.kernel_times(reset=True)
+            lt = sph.Times()
+            torch.cuda.synchronize()
+            l0 = time.perf_counter()
+            for _ in range(K):
+                lsim.simulateAndTime(lt) if args.mode == "time" else lsim.simulate()
+            lsim.sync()
+            result["linked_elapsed"] = time.perf_counter() - l0
+            result["linked_kt"] = lsim.kernel_times()
+            lsim.close()
+        if args.math == "strict" and args.sweep not in ("direct", "linked") and not args.no_fast_leg:
             # secondary figure: the same K steps in SPH_MATH_FAST (not `value`)
             fsim = sph.Simulator(s, sweep=args.sweep, device=local_rank, math="fast")
             fsim.setup()
@@ -192,6 +213,7 @@ def main():
         pairs = kt.pair_tests / steps if kt.pair_tests else None
         achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
         roof = {"bound": "hbm", "kernel": {"lds": "k_density_lds", "direct": "k_density_direct",
+                                                   "linked": "k_density_linked",
                                                    "list": "k_density_mask_lds"}[args.sweep] + " (computeDensity)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": dens_s * 1e6,
@@ -236,6 +258,21 @@ def main():
                                 "note": "SPH_MATH_FAST (FMA + approximate rcp/rsq): not bit-exact; max relative "
                                         "position error 8.1e-7 after 100 steps of -n 8192 -i grid vs the oracle "
                                         "(north-star tolerance 1e-5; tests/test_gpu_parity.py). Not `value`."}
+        if "linked_elapsed" in result:
+            lk = result["linked_kt"]
+            lst = max(int(lk.steps), 1)
+            out["reference_structure"] = {
+                "value": result["n_total"] * K / result["linked_elapsed"], "unit": "particle-steps/s",
+                "ms_per_step": result["linked_elapsed"] / K * 1e3,
+                "kernel_ms_per_step": {"grid": (lk.hash + lk.sort + lk.gather) / lst * 1e3,
+                                       "density": lk.density / lst * 1e3,
+                                       "force_integrate": lk.force / lst * 1e3},
+                "note": "SPH_SWEEP_LINKED: the reference's main-branch neighbour structure (one atomically "
+                        "built linked list per cell, no sort; simulator.cu:44-55,133-147) written for this "
+                        "GPU with the library's float4 streams -- the closest thing to 'the reference's "
+                        "algorithm on MI355X' that can be run (the CUDA source cannot). Same K steps, same "
+                        "input; summation order is a race, results match the oracle to 1e-5 relative "
+                        "(tests/test_gpu_linked.py). Not `value`."}
         tr = load_traffic(result["n_total"], args) if world == 1 else None
         if tr:
             roof["traffic"] = tr["bytes_per_launch"]

@@ -7,7 +7,7 @@ _LIB_NAME = "libsph_hip.so"
 
 SPH_MATH_STRICT, SPH_MATH_FAST = 0, 1
 SPH_SWEEP_LIST, SPH_SWEEP_DIRECT, SPH_SWEEP_LDS = 0, 1, 2
-SWEEPS = {"list": 0, "direct": 1, "lds": 2}
+SWEEPS = {"list": 0, "direct": 1, "lds": 2, "linked": 3}
 SPH_FLAG_COUNT_PAIRS, SPH_FLAG_STORE_FORCE, SPH_FLAG_NO_READBACK = 1, 2, 4
 SPH_FLAG_EXTERNAL_STATE = 8
 

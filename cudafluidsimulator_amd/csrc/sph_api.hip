@@ -333,6 +333,8 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.maskCursor = h->maskCursor;
     A.maskCapacity = h->maskCapacity;
     A.pv8 = h->pv8;
+    A.listHead = reinterpret_cast<const int *>(h->cellRange);
+    A.listNext = reinterpret_cast<const int *>(h->ws.vals[0]);
     return A;
 }
 
@@ -544,13 +546,18 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
         delete h;
         return fail(nullptr, SPH_EINVAL, "unknown math_mode");
     }
-    if (h->opt.sweep < SPH_SWEEP_LIST || h->opt.sweep > SPH_SWEEP_LDS) {
+    if (h->opt.sweep < SPH_SWEEP_LIST || h->opt.sweep > SPH_SWEEP_LINKED) {
         delete h;
         return fail(nullptr, SPH_EINVAL, "unknown sweep variant");
     }
-    if (h->opt.math_mode == SPH_MATH_FAST && h->opt.sweep == SPH_SWEEP_DIRECT) {
+    if (h->opt.math_mode == SPH_MATH_FAST &&
+        (h->opt.sweep == SPH_SWEEP_DIRECT || h->opt.sweep == SPH_SWEEP_LINKED)) {
         delete h;
-        return fail(nullptr, SPH_EINVAL, "SPH_MATH_FAST does not exist for SPH_SWEEP_DIRECT");
+        return fail(nullptr, SPH_EINVAL, "SPH_MATH_FAST does not exist for SPH_SWEEP_DIRECT/LINKED");
+    }
+    if (h->opt.sweep == SPH_SWEEP_LINKED && (h->opt.flags & SPH_FLAG_EXTERNAL_STATE)) {
+        delete h;
+        return fail(nullptr, SPH_EINVAL, "SPH_SWEEP_LINKED is single-domain only");
     }
     h->n = settings->numParticles;
     h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
@@ -640,6 +647,23 @@ int sph_phase_grid(sph_handle *h) {
     StepEvents *ev = h->curEv;
     const int c = h->cur, n = h->n;
     if (ev) HIPCHK(h, hipEventRecord(ev->e[0], s));
+    if (h->opt.sweep == SPH_SWEEP_LINKED) {
+        // the reference's grid: list heads reset (kernelResetGrid :321-326), then one
+        // atomic push per particle (kernelBuildGrid :133-147).  No sort, no gather:
+        // the streams stay where they are, in particle-id order.
+        int *head = reinterpret_cast<int *>(h->cellRange);
+        int *next = reinterpret_cast<int *>(h->ws.vals[0]);
+        HIPCHK(h, hipMemsetAsync(head, 0xFF, (size_t)h->P.numCells * sizeof(int), s));
+        if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
+        if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
+        sph_launch_link_build(h->P, h->pos4[c], head, next, n, s);
+        if (ev) HIPCHK(h, hipEventRecord(ev->e[3], s));
+        HIPCHK(h, hipGetLastError());
+        h->sorted = c;
+        h->gridValid = false; // no cell-range table in this mode
+        h->phase = 1;
+        return SPH_OK;
+    }
     // kernelResetGrid (simulator.cu:321-326,492-495): 8 MB memset, not 10^6 blocks
     HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
     sph_launch_hash(h->P, h->pos4[c], h->ws.keys[0], h->ws.vals[0], n, s);
@@ -754,6 +778,8 @@ int sph_step(sph_handle *h, SphTimes *times) {
 
 int sph_apply_click(sph_handle *h, int mx, int my) {
     if (!h) return SPH_EINVAL;
+    if (h->opt.sweep == SPH_SWEEP_LINKED)
+        return fail(h, SPH_ESTATE, "the click impulse is not available with SPH_SWEEP_LINKED");
     if (!h->gridValid || h->phase != 0 || h->stepIndex == 0)
         return fail(h, SPH_ESTATE, "click needs a completed step (it reuses that step's grid)");
     sph_launch_click(h->P, h->cellRange, h->vel4[h->cur], mx, my, h->compute);

@@ -91,7 +91,15 @@ struct SweepArgs {
     unsigned long long *maskCursor;   // words handed out this step
     unsigned long long maskCapacity;  // pool size in words
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
+    // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
+    const int *listHead;              // [numCells] first particle of the cell or -1
+    const int *listNext;              // [n] next particle of the same cell or -1
 };
+// ---- linked-list backend (sweeps_linked.hip) ----
+void sph_launch_link_build(const DevParams &P, const float4 *pos4, int *head, int *next, int n,
+                           hipStream_t s);
+void sph_launch_density_linked(const DevParams &P, const SweepArgs &A, hipStream_t s);
+void sph_launch_force_linked(const DevParams &P, const SweepArgs &A, hipStream_t s);
 void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s);
 void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s);
 void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode,

@@ -435,6 +435,8 @@ void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode, in
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
     if (sweep == 0)
         sph_launch_density_list(P, A, mathMode, s);
+    else if (sweep == 3)
+        sph_launch_density_linked(P, A, s); // strict only (reference structure)
     else if (sweep == 1)
         k_density_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
     else if (mathMode == 1)
@@ -450,6 +452,8 @@ void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode, int 
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
     if (sweep == 0)
         sph_launch_force_list(P, A, mathMode, s);
+    else if (sweep == 3)
+        sph_launch_force_linked(P, A, s);
     else if (sweep == 1)
         k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
     else if (mathMode == 1)

@@ -62,7 +62,14 @@ enum {
     SPH_SWEEP_LIST = 0,   /* production: LDS-staged density sweep records one hit bit per
                              candidate, the force sweep walks the recorded hits */
     SPH_SWEEP_DIRECT = 1, /* check path: one thread per particle, direct global loads */
-    SPH_SWEEP_LDS = 2     /* LDS-staged window in both sweeps, hit FIFO in the force sweep */
+    SPH_SWEEP_LDS = 2,    /* LDS-staged window in both sweeps, hit FIFO in the force sweep */
+    SPH_SWEEP_LINKED = 3  /* the reference's own neighbour structure: no sort, one atomically
+                             built linked list per cell (simulator.cu:44-55,133-147), walked
+                             as in :163-189/:207-251.  Summation order is a race, so results
+                             match the oracle to rounding only, and differ run to run.  Kept to
+                             time "the reference's algorithm on MI355X"; strict math, single
+                             domain only; sph_apply_click / sph_download_grid / the slab entry
+                             points return SPH_ESTATE. */
 };
 enum {
     SPH_FLAG_COUNT_PAIRS = 1, /* accumulate the candidate pair-test count per step */
