@@ -49,7 +49,10 @@ void Simulator::setup() {
     o.struct_size = (int32_t)sizeof o;
     o.device = -1;
     if (const char *e = getenv("SPH_SWEEP"))
-        o.sweep = strcmp(e, "direct") == 0 ? SPH_SWEEP_DIRECT : strcmp(e, "lds") == 0 ? SPH_SWEEP_LDS : SPH_SWEEP_LIST;
+        o.sweep = strcmp(e, "direct") == 0   ? SPH_SWEEP_DIRECT
+                  : strcmp(e, "lds") == 0    ? SPH_SWEEP_LDS
+                  : strcmp(e, "linked") == 0 ? SPH_SWEEP_LINKED
+                                             : SPH_SWEEP_LIST;
     int rc = sph_create(&s, &o, &impl);
     check(NULL, rc, "sph_create");
     check(impl, sph_setup(impl), "sph_setup");
