@@ -54,21 +54,32 @@ def parse():
 
 def cpu_baseline(n, random_init, steps):
     """The CPU oracle (kind 'port': the reference has no CPU path and its CUDA
-    source cannot be built here) on the host's cores, bounded sample."""
+    source cannot be built here) on the host's cores, bounded sample.  A GPU box
+    gives a job a CPU share smaller than the core count it reports, so two team
+    sizes are timed -- 16 threads and every reported core -- and the faster one is
+    the baseline (`cores` = the threads of that run)."""
     from oracle import oracle as O
-    sim = O.OracleSim(n, random_init)
-    sim.setup()
-    t0 = time.perf_counter()
-    sim.step(steps)
-    dt = time.perf_counter() - t0
-    sim.close()
-    out = {"value": n * steps / dt, "unit": "particle-steps/s", "cores": O.num_threads(),
+
+    def run(threads):
+        O.set_num_threads(threads)
+        sim = O.OracleSim(n, random_init)
+        sim.setup()
+        t0 = time.perf_counter()
+        sim.step(steps)
+        dt = time.perf_counter() - t0
+        sim.close()
+        return dt
+
+    ncpu = os.cpu_count() or 1
+    legs = {t: run(t) for t in sorted({min(16, ncpu), ncpu})}
+    threads, dt = min(legs.items(), key=lambda kv: kv[1])
+    out = {"value": n * steps / dt, "unit": "particle-steps/s", "cores": threads,
            "kind": "port",
            "sample": f"first {steps} steps of -n {n} -i {'random' if random_init else 'grid'} "
                      f"(of the 100-step run; later steps cost up to 4.7x more), "
-                     f"OpenMP oracle, {dt:.1f} s"}
+                     f"OpenMP oracle, {dt:.1f} s; team sizes tried: "
+                     + ", ".join(f"{t} threads {n * steps / d:.3g}/s" for t, d in legs.items())}
     # the same oracle on ONE core (bounded: the first step only)
-    all_threads = O.num_threads()
     O.set_num_threads(1)
     sim = O.OracleSim(n, random_init)
     sim.setup()
@@ -76,7 +87,7 @@ def cpu_baseline(n, random_init, steps):
     sim.step(1)
     dt1 = time.perf_counter() - t0
     sim.close()
-    O.set_num_threads(all_threads)
+    O.set_num_threads(threads)
     out["single_thread"] = {"value": n / dt1, "unit": "particle-steps/s", "cores": 1,
                             "sample": f"first step only, {dt1:.1f} s"}
     return out

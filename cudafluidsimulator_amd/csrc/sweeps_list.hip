@@ -73,6 +73,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 // eighth trip.  A run whose union does not fit the slice (dense cells) is walked
 // in the same lock-step straight from global memory.
 // ---------------------------------------------------------------------------
+#ifndef SL_ADDC
+#define SL_ADDC 1
+#endif
 template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
@@ -127,6 +130,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 #if SL_VCONST
     float h2v = P.h2, dcv = P.dcoef, cut2v = P.cut2;
     asm volatile("" : "+v"(h2v), "+v"(dcv), "+v"(cut2v));
+#endif
+#if SL_ADDC
+    float cut2r = P.cut2; // in a VGPR once: the compare below cannot take an SGPR there
+    asm volatile("" : "+v"(cut2r));
 #endif
     int pend = 0; // words of this lane waiting in wbuf
     // write this lane's pending words (4 at a time) and empty its buffer
@@ -215,15 +222,29 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
                         const float diff = fmaxf(h2 - dist2, 0.f);
                         rho += SPH_MASS * (dcoef * diff * diff * diff);
                     }
+#if SL_ADDC
+                    // hit bit shifted in through the carry: m = 2m + !(dist2 > cut2), two
+                    // VALU ops per candidate instead of mov + cmp + cndmask + or.  The word
+                    // fills from the top, so it is bit-reversed once when it is handed over.
+                    asm("v_cmp_ngt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                        : "+v"(m)
+                        : "v"(dist2), "v"(cut2r)
+                        : "vcc");
+#else
                     const uint32_t bit = 1u << ((k + u) & 31); // wave-uniform
                     m |= !(dist2 > cut2) ? bit : 0u;
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
                 if (((k + SW_UNROLL) & 31) == 0) { // a whole word is complete (wave-uniform)
                     if (ok && m != 0) { // empty words are not stored
                         wbuf[pend++ * SPH_WAVE] = (uint32_t)(jsr + (k & ~31));
+#if SL_ADDC
+                        wbuf[pend++ * SPH_WAVE] = __builtin_bitreverse32(m);
+#else
                         wbuf[pend++ * SPH_WAVE] = m;
+#endif
                     }
                     m = 0;
                     if (__ballot(pend >= SL_WBUF)) flush_words();
@@ -256,7 +277,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
             if ((k & 31) != 0) { // last, partial word
                 if (ok && m != 0) {
                     wbuf[pend++ * SPH_WAVE] = (uint32_t)(jsr + (k & ~31));
+#if SL_ADDC
+                    wbuf[pend++ * SPH_WAVE] = __builtin_bitreverse32(m) >> (32 - (k & 31));
+#else
                     wbuf[pend++ * SPH_WAVE] = m;
+#endif
                 }
                 if (__ballot(pend >= SL_WBUF)) flush_words();
             }

@@ -49,6 +49,12 @@ def lib():
     if _lib is not None:
         return _lib
     build()
+    # A GPU box hands a job a CPU *share* (about 16 cores of a 128-core host) that
+    # neither os.cpu_count() nor the affinity mask shows.  A 128-thread OpenMP team
+    # spinning at every barrier on that share can make a one-second test take minutes,
+    # so the team is capped (ORACLE_MAX_THREADS, default 16) and waits passively.
+    # Results do not depend on the thread count.
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     L = C.CDLL(_LIB_PATH)
     fp = C.POINTER(C.c_float)
     u32p = C.POINTER(C.c_uint32)
@@ -82,6 +88,9 @@ def lib():
     L.oracle_sim_last_pair_tests.restype = C.c_uint64
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_num_threads.argtypes = [C.c_int]
+    cap = int(os.environ.get("ORACLE_MAX_THREADS", "16"))
+    if cap > 0 and L.oracle_num_threads() > cap:
+        L.oracle_set_num_threads(cap)
     _lib = L
     return L
 
