@@ -323,11 +323,32 @@ def step_distributed(slab, tr):
     slab.force()
 
 
-def run_loopback(slabs, steps):
+def nccl_self_copy(dist, group=None):
+    """A `copy` for run_loopback that moves every message of a round through RCCL:
+    one rank sends to ITSELF (RCCL implements self send/recv as a device copy), in
+    one batch_isend_irecv per round like DistTransport.  With a world of one rank it
+    exercises the real tensors (views, offsets, dtypes) against torch's RCCL
+    point-to-point API on a one-GPU box."""
+    def copy(pairs):
+        me = dist.get_rank(group)
+        ops = []
+        for src, _ in pairs:
+            ops.append(dist.P2POp(dist.isend, src, me, group=group))
+        for _, dst in pairs:
+            ops.append(dist.P2POp(dist.irecv, dst, me, group=group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+    return copy
+
+
+def run_loopback(slabs, steps, copy=None):
     """Step several slabs of ONE process in lock-step (1-GPU / CPU testing):
     messages are delivered by tensor copies in the same order DistTransport
-    would deliver them."""
+    would deliver them (`copy`: a callable taking the round's (src, dst) pairs,
+    default plain tensor copies)."""
     def deliver(all_sends, all_recvs):
+        pairs = []
         for r, slab_sends in enumerate(all_sends):
             for d in (DOWN, UP):
                 out = [x for dd, x in _nonempty(slab_sends) if dd == d]
@@ -338,7 +359,12 @@ def run_loopback(slabs, steps):
                 assert len(out) == len(inn), "send/recv plans disagree"
                 for src, dst in zip(out, inn):
                     assert src.shape == dst.shape, (src.shape, dst.shape)
-                    dst.copy_(src)
+                    pairs.append((src, dst))
+        if copy is not None:
+            copy(pairs)
+        else:
+            for src, dst in pairs:
+                dst.copy_(src)
 
     for _ in range(steps):
         counts = [s.local_sort() for s in slabs]

@@ -155,6 +155,39 @@ def test_hip_loopback_slabs_equal_single_domain(world, sweep):
 
 
 @pytest.mark.gpu
+def test_hip_slabs_exchanging_through_rccl_self_send():
+    """The slab messages -- the very tensor views DistTransport posts -- through
+    torch.distributed's RCCL point-to-point API: a world of ONE rank sending to itself
+    (all a one-GPU box allows; >1 rank per GPU is refused by RCCL)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, steps, world = 60000, 6, 3
+        pos, vel = moving_state(n, 9)
+        settings = sph.default_settings(n, False)
+        p4, v4 = S.pack_state(pos, vel)
+        bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+        slabs = []
+        for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
+            sl = S.Slab(S.HipSlabBackend(settings, n, device=0), r, world, zlo, zhi, 100)
+            sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
+            slabs.append(sl)
+        S.run_loopback(slabs, steps, copy=S.nccl_self_copy(dist))
+        torch.cuda.synchronize()
+        got = collect([tuple(x.cpu().numpy() for x in sl.owned()) for sl in slabs], n)
+        want = reference_run(pos, vel, steps)
+        assert_bit_equal(got[0], want["pos"], "pos")
+        assert_bit_equal(got[1], want["vel"], "vel")
+        for sl in slabs:
+            sl.b.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_hip_slab_reference_initialiser_4_slabs():
     n, steps, world = 262144, 6, 4
     settings = sph.default_settings(n, True)
