@@ -79,6 +79,8 @@ struct sph_handle {
     int *boundsDev = nullptr, *boundsHost = nullptr;
     PairEvent pairs[kPairRing];
     int pairHead = 0;
+    int zLayers = 0;        // occupied z-layers of the (owned) particles: sizes xcd_tile()'s chunks
+    int tileChunkEnv = -1;  // SPH_TILE_CHUNK: -1 auto, 0 contiguous eighths, >0 tiles per chunk
     bool ready = false;     // state uploaded
     bool gridValid = false; // sorted streams + cell table match `sorted`
     int phase = 0;          // 0 idle, 1 grid done, 2 density done, 3 force done
@@ -280,9 +282,12 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     const float hh = h->settings.h;
     const int D = h->P.D;
     std::vector<float4> p4((size_t)n), v4((size_t)n);
+    int zmin = D, zmax = -1;
     for (int i = 0; i < n; ++i) {
         float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
         int cx = (int)(x / hh), cy = (int)(y / hh), cz = (int)(z / hh);
+        zmin = cz < zmin ? cz : zmin;
+        zmax = cz > zmax ? cz : zmax;
         if (!(x == x && y == y && z == z) || cx < 0 || cx >= D || cy < 0 || cy >= D ||
             cz < 0 || cz >= D || x < 0.f || y < 0.f || z < 0.f)
             return fail(h, SPH_EINVAL, "position outside the simulation box");
@@ -303,6 +308,7 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
                             hipMemcpyHostToDevice));
     }
     HIPCHK(h, hipDeviceSynchronize());
+    h->zLayers = zmax >= zmin ? zmax - zmin + 1 : 0;
     h->ready = true;
     h->gridValid = false;
     h->phase = 0;
@@ -310,6 +316,14 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     h->stepIndex = 0;
     h->copyPending[0] = h->copyPending[1] = false;
     return SPH_OK;
+}
+
+// xcd_tile() chunk: an eighth of one z-layer's worth of 256-particle tiles.
+int tile_chunk(const sph_handle *h, int count, int layers) {
+    if (h->tileChunkEnv >= 0) return h->tileChunkEnv;
+    if (layers <= 0) return 0;
+    const long long tiles = ((long long)count + 255) / 256;
+    return (int)(tiles / (8ll * layers)); // 0 (contiguous eighths) when a layer is under 8 tiles
 }
 
 SweepArgs make_sweep_args(sph_handle *h) {
@@ -328,6 +342,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.i_begin = 0;
     A.i_end = h->n;
     A.n_all = h->n;
+    A.tileChunk = tile_chunk(h, h->n, h->zLayers);
     A.maskPool = h->maskPool;
     A.maskOff = h->maskOff;
     A.maskCursor = h->maskCursor;
@@ -427,6 +442,8 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
                       h->ws.vals[res], h->ws.keys[res], h->pos4[src_buf ^ 1],
                       h->vel4[src_buf ^ 1], h->pv8, h->cellRange, count, s);
     HIPCHK(h, hipEventRecord(pe->b, s));
+    if (nthr == 4) // [zlo, zlo+1, zhi-1, zhi] * D*D: the slab's owned z-layers
+        h->zLayers = (int)((thresholds[3] - thresholds[0]) / (uint32_t)(h->P.D * h->P.D));
     if (nthr > 0) {
         Thresholds T{};
         for (int k = 0; k < nthr; ++k) T.v[k] = thresholds[k];
@@ -452,6 +469,7 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     A.i_begin = i_begin;
     A.i_end = i_end;
     A.n_all = n_all;
+    A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
     A.force_out = nullptr;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
     PairEvent *pe = nullptr;
@@ -472,6 +490,7 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     A.i_begin = i_begin;
     A.i_end = i_end;
     A.n_all = n_all;
+    A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
     A.force_out = nullptr;
     PairEvent *pe = nullptr;
     if ((rc = pair_begin(h, &h->kt.force, &pe))) return rc;
@@ -561,6 +580,7 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
     }
     h->n = settings->numParticles;
     h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
+    if (const char *e = getenv("SPH_TILE_CHUNK")) h->tileChunkEnv = atoi(e); // tuning studies
     fill_params(h);
     int rc = SPH_OK;
     do {
@@ -851,12 +871,17 @@ int sph_load_state(sph_handle *h, const char *path) {
     fclose(f);
     if (!ok) return fail(h, SPH_EINVAL, "not a snapshot / truncated");
     std::vector<char> seen(n ? n : 1, 0);
+    int zmin = h->P.D, zmax = -1;
     for (size_t i = 0; i < n; ++i) { // ids must be a permutation: they index devicePosition
         uint32_t id;
         memcpy(&id, &p4[i].w, 4);
         if (id >= n || seen[id]) return fail(h, SPH_EINVAL, "corrupt snapshot (ids)");
         seen[id] = 1;
+        const int cz = (int)(p4[i].z / h->settings.h);
+        zmin = cz < zmin ? cz : zmin;
+        zmax = cz > zmax ? cz : zmax;
     }
+    h->zLayers = zmax >= zmin ? zmax - zmin + 1 : 0;
     HIPCHK(h, hipStreamSynchronize(h->compute));
     HIPCHK(h, hipStreamSynchronize(h->copy));
     h->cur = 0;

@@ -85,6 +85,7 @@ struct SweepArgs {
     unsigned long long *stampCounter; // diagnostic builds only (same buffer)
     int i_begin, i_end;       // owned range (whole array for one domain)
     int n_all;
+    int tileChunk;            // xcd_tile(): 256-particle tiles per chunk (1/8 z-layer), 0 = eighths
     // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
     uint32_t *maskPool;               // pool of 32-candidate mask words
     uint32_t *maskOff;                // per sorted particle: {first dword or ~0u, dwords}

@@ -196,14 +196,35 @@ __device__ __forceinline__ void store_particle(const SweepArgs &A, int i, float4
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2),
-// so consecutive blockIdx values land on different XCDs.  Consecutive tiles of
-// the cell-sorted stream share most of their neighbour window; remap so that
-// every XCD walks ONE contiguous eighth of the stream and its L2 sees each
-// window once (speed only -- any placement gives the same result).
-__device__ __forceinline__ int xcd_tile(int b, int nb) {
-    const int xcd = b & 7, idx = b >> 3;
-    const int q = nb >> 3, rem = nb & 7;
-    return xcd * q + min(xcd, rem) + idx;
+// so consecutive blockIdx values land on different XCDs, and an XCD keeps about
+// 170 workgroups (43 K particles) in flight.  A tile of the cell-sorted stream
+// gathers from three z-layers (its own and the two next to it), each 1/L of the
+// stream.  Two placements (speed only -- any placement gives the same result):
+//  * C == 0: every XCD walks ONE contiguous eighth of the stream.  Its resident
+//    tiles then span most of a layer and its L2 has to hold three whole layers
+//    (5 MB of (pos4, vel4) records at n = 4 M): it does not, and every record is
+//    fetched from memory about three times.
+//  * C > 0 (tiles per chunk, = 1/8 of a z-layer): the stream is cut into groups
+//    of 8 chunks and chunk x of every group goes to XCD x.  All XCDs then move
+//    through the layers together, each on its own y-band, and an XCD's working
+//    set is that band of the ~9 layers it has in flight (1.8 MB): the records of
+//    the layers above and below are still in its L2 when it reaches them.
+__device__ __forceinline__ int xcd_tile(int b, int nb, int C) {
+    int base = 0, R = nb, r = b;
+    if (C > 0) {
+        const int G = 8 * C;
+        const int ng = nb / G, g = b / G;
+        if (g < ng) {
+            r = b - g * G;
+            return g * G + (r & 7) * C + (r >> 3);
+        }
+        base = ng * G; // the tail (< one group) is dealt in contiguous eighths
+        R = nb - base;
+        r = b - base;
+    }
+    const int xcd = r & 7, idx = r >> 3;
+    const int q = R >> 3, rem = R & 7;
+    return base + xcd * q + min(xcd, rem) + idx;
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {

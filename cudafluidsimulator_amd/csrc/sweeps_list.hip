@@ -91,7 +91,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 #if SW_STAMPS
     unsigned long long accStage = 0, accTest = 0;
 #endif
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
@@ -337,7 +337,7 @@ __launch_bounds__(SW_THREADS, SL_K2_WAVES)
 __launch_bounds__(SW_THREADS)
 #endif
 void k_force_list(DevParams P, SweepArgs A) {
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     const int iSafe = valid ? i : A.i_begin;
     float4 pi = A.pos4[iSafe];
@@ -356,7 +356,7 @@ void k_force_list(DevParams P, SweepArgs A) {
     // ds_read_b128 instead of a 64-address global gather.
     __shared__ float4 winAll[SW_WAVES][2 * SL_WINDOW];
     float4 *win = winAll[threadIdx.x >> 6];
-    const int tile0 = A.i_begin + xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + (threadIdx.x & ~63);
+    const int tile0 = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + (threadIdx.x & ~63);
     const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
     {
