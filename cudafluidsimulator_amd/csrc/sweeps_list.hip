@@ -326,6 +326,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 // ---------------------------------------------------------------------------
 // force + integrate over the recorded hits
 // ---------------------------------------------------------------------------
+// Measured dead end: non-temporal (`nt`) loads of the hit stream and stores of it in the
+// density sweep, meant to keep the stream from pushing neighbour records out of L2:
+// force sweep 1.30 -> 1.66 ms, density 1.12 -> 1.17 ms (an nt load does not keep the
+// lane's line for its next 8-byte pair either).
 #ifndef SL_K2_WAVES
 #define SL_K2_WAVES 0 // >0: ask for that many resident waves per SIMD (caps the VGPR budget)
 #endif
