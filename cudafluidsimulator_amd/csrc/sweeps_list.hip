@@ -42,6 +42,9 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
                       // (0 = off).  Measured: 1.60 -> 1.49 ms; 256 records or three rows
                       // (12 KiB per wave) lose more to occupancy than they save.
 #endif
+#ifndef SL_PAIRQ
+#define SL_PAIRQ 2 // 0, 2 or 4: the force sweep refills that many pairs at a time (aligned lane streams)
+#endif
 #ifndef SL_VCONST
 #define SL_VCONST 0
 #endif
@@ -69,8 +72,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 // LDS and every lane walks its own range from its first candidate, four per
 // trip.  All lanes of the wave are at the same candidate ORDINAL k at any time,
 // so the mask bit position (k & 31) is wave-uniform: recording a hit costs a
-// compare, a select of a scalar bit and an OR, and whole words are flushed every
-// eighth trip.  A run whose union does not fit the slice (dense cells) is walked
+// compare and an add-with-carry (m = 2m + hit), and whole words are bit-reversed
+// and flushed every eighth trip.  A run whose union does not fit the slice (dense cells) is walked
 // in the same lock-step straight from global memory.
 // ---------------------------------------------------------------------------
 #ifndef SL_ADDC
@@ -105,6 +108,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
         words += 2u * ((uint32_t)(je[r] - js[r] + 31) >> 5);
         pairs += (uint32_t)(je[r] - js[r]);
     }
+#if SL_PAIRQ
+    words = (words + 2u * SL_PAIRQ - 1u) & ~(2u * SL_PAIRQ - 1u); // lane streams start on a load boundary
+#endif
     const uint32_t incl = wave_incl_scan_u32(words, lane);
     const uint32_t total = __shfl(incl, 63);
     unsigned long long base = 0;
@@ -382,6 +388,40 @@ void k_force_list(DevParams P, SweepArgs A) {
         // pair; (jbn, mn): the next pair, already in flight.  pop() returns the next
         // hit's sorted index, or the particle itself once the stream is exhausted
         // (dist = 0 gates every term: exact no-op).
+#if SL_PAIRQ
+        // SL_PAIRQ pairs per refill (16-byte loads): fewer stream loads and cache-line touches
+        const uint4 *stream4 = reinterpret_cast<const uint4 *>(A.maskPool + off);
+        const int nq = (npairs + SL_PAIRQ - 1) / SL_PAIRQ;
+        int wq = 0;
+        uint32_t m = 0, mq[SL_PAIRQ];
+        int jb = 0, jq[SL_PAIRQ];
+#pragma unroll
+        for (int u = 0; u < SL_PAIRQ; ++u) { mq[u] = 0; jq[u] = 0; }
+        bool live = true;
+        auto fetch = [&]() {
+            if (wq < nq) {
+#pragma unroll
+                for (int u = 0; u < SL_PAIRQ; u += 2) {
+                    const uint4 t = stream4[wq * (SL_PAIRQ / 2) + u / 2];
+                    jq[u] = (int)t.x;
+                    mq[u] = (SL_PAIRQ * wq + u < npairs) ? t.y : 0u; // beyond the count: padding
+                    jq[u + 1] = (int)t.z;
+                    mq[u + 1] = (SL_PAIRQ * wq + u + 1 < npairs) ? t.w : 0u;
+                }
+                ++wq;
+            }
+        };
+        fetch();
+        auto pop = [&]() -> int {
+            if (m == 0) { // next pair; stored masks are never 0, so mq[0] == 0 means "queue empty"
+                m = mq[0];
+                jb = jq[0];
+#pragma unroll
+                for (int u = 0; u + 1 < SL_PAIRQ; ++u) { mq[u] = mq[u + 1]; jq[u] = jq[u + 1]; }
+                mq[SL_PAIRQ - 1] = 0;
+                if (mq[0] == 0) fetch();
+            }
+#else
         int wi = 0;
         uint32_t m = 0, mn = 0;
         int jb = 0, jbn = 0;
@@ -394,7 +434,12 @@ void k_force_list(DevParams P, SweepArgs A) {
                 mn = 0;
                 if (wi < npairs) { const uint2 t = stream[wi]; jbn = (int)t.x; mn = t.y; ++wi; }
             }
+#endif
+#if SL_PAIRQ
+            live = (m | mq[0]) != 0;
+#else
             live = (m | mn) != 0;
+#endif
             const bool has = m != 0;
             const int b = has ? __builtin_ctz(m) : 0;
             m &= m - 1u; // (0 stays 0)
