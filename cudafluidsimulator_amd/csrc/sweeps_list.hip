@@ -38,9 +38,10 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #define SL_STAMP(var)
 #endif
 #ifndef SL_WINDOW
-#define SL_WINDOW 128 // records around the wave's own particles cached in LDS by the force sweep
-                      // (0 = off).  Measured: 1.60 -> 1.49 ms; 256 records or three rows
-                      // (12 KiB per wave) lose more to occupancy than they save.
+#define SL_WINDOW 160 // records around the wave's own particles cached in LDS by the force sweep
+                      // (0 = off).  Measured: 1.60 -> 1.49 ms with 128; 160 or 192 another 1 %
+                      // (5 KiB per wave still leaves six waves per SIMD); 256 records or three
+                      // rows (12 KiB per wave) lose more to occupancy than they save.
 #endif
 #ifndef SL_PAIRQ
 #define SL_PAIRQ 2 // 0, 2 or 4: the force sweep refills that many pairs at a time (aligned lane streams)
