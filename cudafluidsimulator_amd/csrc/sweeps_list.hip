@@ -43,6 +43,16 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
                       // (5 KiB per wave still leaves six waves per SIMD); 256 records or three
                       // rows (12 KiB per wave) lose more to occupancy than they save.
 #endif
+// Workgroup sizes of the two sweeps.  Their waves are autonomous (no workgroup barrier),
+// but a workgroup's LDS and wave slots are only handed back when its LAST wave ends, and
+// wave times differ with the hit counts: one wave per workgroup measured -1.3 % (density)
+// and -2.7 % (force) against four.
+#ifndef SL_K1_THREADS
+#define SL_K1_THREADS 64
+#endif
+#ifndef SL_K2_THREADS
+#define SL_K2_THREADS 64
+#endif
 #ifndef SL_PAIRQ
 #define SL_PAIRQ 2 // 0, 2 or 4: the force sweep refills that many pairs at a time (aligned lane streams)
 #endif
@@ -81,13 +91,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #define SL_ADDC 1
 #endif
 template <bool FAST>
-__global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, SweepArgs A) {
-    __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
+__global__ __launch_bounds__(SL_K1_THREADS) void k_density_mask_lds(DevParams P, SweepArgs A) {
+    __shared__ float4 stageAll[SL_K1_THREADS / SPH_WAVE][SW_CAP + SW_UNROLL];
     // Finished mask words wait here ([slot][lane]: conflict-free) until a lane has
     // SL_WBUF of them, then leave as 16-byte stores: single-word stores to 64
     // different streams made every word a partial-line write (measured 2.0 GB of
     // WRITE_SIZE per launch for 0.28 GB of masks).
-    __shared__ uint32_t wbufAll[SW_WAVES][SL_WBUF * SPH_WAVE];
+    __shared__ uint32_t wbufAll[SL_K1_THREADS / SPH_WAVE][SL_WBUF * SPH_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
     uint32_t *wbuf = wbufAll[w] + lane;
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 #if SW_STAMPS
     unsigned long long accStage = 0, accTest = 0;
 #endif
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + threadIdx.x;
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K1_THREADS)) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
@@ -346,12 +356,13 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_mask_lds(DevParams P, Sw
 template <bool FAST>
 __global__
 #if SL_K2_WAVES
-__launch_bounds__(SW_THREADS, SL_K2_WAVES)
+__launch_bounds__(SL_K2_THREADS, SL_K2_WAVES)
 #else
-__launch_bounds__(SW_THREADS)
+__launch_bounds__(SL_K2_THREADS)
 #endif
 void k_force_list(DevParams P, SweepArgs A) {
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + threadIdx.x;
+    const int tileIdx = xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K2_THREADS));
+    const int i = A.i_begin + tileIdx * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     const int iSafe = valid ? i : A.i_begin;
     float4 pi = A.pos4[iSafe];
@@ -368,9 +379,9 @@ void k_force_list(DevParams P, SweepArgs A) {
     // hits are neighbours in the particle's own grid row, i.e. within a few dozen
     // slots of the wave's 64 particles in the sorted stream: those are served by
     // ds_read_b128 instead of a 64-address global gather.
-    __shared__ float4 winAll[SW_WAVES][2 * SL_WINDOW];
+    __shared__ float4 winAll[SL_K2_THREADS / SPH_WAVE][2 * SL_WINDOW];
     float4 *win = winAll[threadIdx.x >> 6];
-    const int tile0 = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + (threadIdx.x & ~63);
+    const int tile0 = A.i_begin + tileIdx * blockDim.x + (threadIdx.x & ~63);
     const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
     {
@@ -504,9 +515,9 @@ void k_force_list(DevParams P, SweepArgs A) {
 void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
-    int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-    if (mathMode == 1) k_density_mask_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
-    else k_density_mask_lds<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    int blocks = (cnt + SL_K1_THREADS - 1) / SL_K1_THREADS;
+    if (mathMode == 1) k_density_mask_lds<true><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
+    else k_density_mask_lds<false><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
 }
 
 // Particles whose wave found the mask pool exhausted in the density sweep: test
@@ -554,10 +565,10 @@ void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode,
     const int halo = A.i_begin + (A.n_all - A.i_end);
     if (halo > 0) k_patch_pv8<<<(halo + 255) / 256, 256, 0, s>>>(A.vel4, A.pv8, A.i_begin, A.i_end, A.n_all);
     if (mathMode == 1) {
-        k_force_list<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_list<true><<<(cnt + SL_K2_THREADS - 1) / SL_K2_THREADS, SL_K2_THREADS, 0, s>>>(P, A);
         k_force_fallback<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
     } else {
-        k_force_list<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_list<false><<<(cnt + SL_K2_THREADS - 1) / SL_K2_THREADS, SL_K2_THREADS, 0, s>>>(P, A);
         k_force_fallback<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
     }
 }

@@ -98,6 +98,82 @@ __global__ __launch_bounds__(256) void k_valu(float *out, int iters, float a, fl
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + y0 + y1 + y2 + y3;
 }
 
+
+// Packed variant: candidates staged SoA (x[], y[], z[]), four per trip through three
+// ds_read_b128, arithmetic on float2 pairs (v_pk_add_f32 / v_pk_mul_f32), hit bits
+// through the carry; per-candidate validity applied as a +0/+inf penalty on dist2.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_lds_pk(float *out, int iters, float a, float b) {
+    __shared__ f4 tx[4][68], ty[4][68], tz[4][68];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = lane; k < 68; k += 64) {
+        tx[w][k] = (f4){k * 1e-3f, k * 1.1e-3f, k * 1.2e-3f, k * 1.3e-3f};
+        ty[w][k] = (f4){k * 2e-3f, k * 2.1e-3f, k * 2.2e-3f, k * 2.3e-3f};
+        tz[w][k] = (f4){k * 3e-3f, k * 3.1e-3f, k * 3.2e-3f, k * 3.3e-3f};
+    }
+    __syncthreads();
+    const float px = lane * 1e-3f, py = 0.1f, pz = 0.2f;
+    const f2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz};
+    float rho = 0.f;
+    float hv = a, dv = b, cut = a * 1.0001f;
+    asm volatile("" : "+v"(hv), "+v"(dv), "+v"(cut));
+    const f2 H2 = {hv, hv}, DC = {dv, dv}, MS = {0.02f, 0.02f};
+    unsigned m = 0, acc = 0;
+    int idx = lane >> 3;
+    const int lo = lane & 3, hi = iters * 4 - (lane & 1); // a lane-dependent valid range
+    for (int i = 0; i < iters; ++i) {
+        const f4 X = tx[w][idx & 63], Y = ty[w][idx & 63], Z = tz[w][idx & 63];
+        // validity of the four candidates of this trip as penalties (0 or +inf)
+        const int k0 = 4 * i;
+        f4 pen;
+        pen.x = (k0 + 0 >= lo && k0 + 0 < hi) ? 0.f : __builtin_inff();
+        pen.y = (k0 + 1 >= lo && k0 + 1 < hi) ? 0.f : __builtin_inff();
+        pen.z = (k0 + 2 >= lo && k0 + 2 < hi) ? 0.f : __builtin_inff();
+        pen.w = (k0 + 3 >= lo && k0 + 3 < hi) ? 0.f : __builtin_inff();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f2 xj = h ? X.zw : X.xy, yj = h ? Y.zw : Y.xy, zj = h ? Z.zw : Z.xy;
+            const f2 pn = h ? pen.zw : pen.xy;
+            const f2 dx = PX - xj, dy = PY - yj, dz = PZ - zj;
+            f2 d2 = dx * dx + dy * dy + dz * dz;
+            d2 = d2 + pn;
+            f2 diff = H2 - d2;
+            diff.x = fmaxf(diff.x, 0.f);
+            diff.y = fmaxf(diff.y, 0.f);
+            const f2 t = MS * (DC * diff * diff * diff);
+            rho += t.x;
+            rho += t.y;
+            asm("v_cmp_ngt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2.x), "v"(cut) : "vcc");
+            asm("v_cmp_ngt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2.y), "v"(cut) : "vcc");
+        }
+        if ((i & 7) == 7) { acc ^= m; m = 0; }
+        idx += 1;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = rho + (float)acc;
+}
+
+void run_lds_pk(int wavesPerSimd) {
+    int blocks = 256 * wavesPerSimd;
+    float *out;
+    (void)hipMalloc(&out, blocks * 256 * sizeof(float));
+    int iters = 40000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k_lds_pk<<<blocks, 256>>>(out, 100, 0.01f, 1e3f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    k_lds_pk<<<blocks, 256>>>(out, iters, 0.01f, 1e3f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double tests = (double)iters * 4;
+    double cyc = ms * 1e-3 * 2.4e9;
+    printf("%-14s waves/SIMD %d : %.3f ms, %.1f cycles(@2.4GHz) per wave-test per SIMD\n", "lds-soa-packed", wavesPerSimd, ms,
+           cyc / (tests * wavesPerSimd));
+    (void)hipFree(out);
+}
+
 template <int MODE>
 void run(const char *name, int instrPerInner, int wavesPerSimd) {
     int blocksPerCU = wavesPerSimd; // 256 threads = 4 waves = 1 wave per SIMD
@@ -126,8 +202,7 @@ int main() {
     for (int w : {1, 2, 4, 8}) run_lds<0>("lds-b128", w);
     for (int w : {1, 2, 4, 8}) run_lds<1>("lds-b128-sel", w);
     for (int w : {1, 2, 4, 8}) run_lds<2>("lds-b96", w);
-    for (int w : {2, 8}) run<1>("density-noLDS", 18, w);
-    return 0;
+    for (int w : {1, 2, 4, 6, 8}) run_lds_pk(w);
     for (int w : {1, 2, 4, 8}) run<0>("mul/add", 8, w);
     for (int w : {1, 2, 4, 8}) run<1>("density", 18, w);
     for (int w : {1, 2, 4, 8}) run<2>("fma", 8, w);
