@@ -7,7 +7,9 @@
 
 #define SW_THREADS 256
 #define SW_WAVES (SW_THREADS / SPH_WAVE)
+#ifndef SW_UNROLL
 #define SW_UNROLL 4 // candidates per trip of a lock-step walk
+#endif
 #ifndef SW_CAP
 #define SW_CAP 256  // staged candidates per chunk per wave (4 KiB)
 #endif
