@@ -83,6 +83,51 @@ void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                                                    pos_out, vel_out, pv8, cellRange, n);
 }
 
+// ---- slab path: stable partition by key class (which segment of the slab's key
+// range a particle's NEW cell falls in) instead of a full sort.  class = number of
+// thresholds <= key; the one-pass radix sort on that small key keeps the previous
+// order inside every class, which is all the exchange needs (the combined array is
+// sorted by the full key afterwards).
+__global__ __launch_bounds__(256) void k_classify(DevParams P, const float4 *__restrict__ pos4,
+                                                  Thresholds thr, int nthr,
+                                                  uint32_t *__restrict__ keys,
+                                                  uint32_t *__restrict__ vals, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos4[i];
+    int3 c = grid_cell(P, p.x, p.y, p.z);
+    const uint32_t key = (uint32_t)(c.x + c.y * P.D + c.z * P.D * P.D);
+    uint32_t cls = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cls += (k < nthr && key >= thr.v[k]) ? 1u : 0u;
+    keys[i] = cls;
+    vals[i] = (uint32_t)i;
+}
+
+void sph_launch_classify(const DevParams &P, const float4 *pos4, Thresholds thr, int nthr,
+                         uint32_t *keys, uint32_t *vals, int n, hipStream_t s) {
+    if (n <= 0) return;
+    k_classify<<<(n + 255) / 256, 256, 0, s>>>(P, pos4, thr, nthr, keys, vals, n);
+}
+
+__global__ __launch_bounds__(256) void k_gather_plain(const float4 *__restrict__ pos_in,
+                                                      const float4 *__restrict__ vel_in,
+                                                      const uint32_t *__restrict__ perm,
+                                                      float4 *__restrict__ pos_out,
+                                                      float4 *__restrict__ vel_out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = perm[i];
+    pos_out[i] = pos_in[src];
+    vel_out[i] = vel_in[src];
+}
+
+void sph_launch_gather_plain(const float4 *pos_in, const float4 *vel_in, const uint32_t *perm,
+                             float4 *pos_out, float4 *vel_out, int n, hipStream_t s) {
+    if (n <= 0) return;
+    k_gather_plain<<<(n + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, pos_out, vel_out, n);
+}
+
 __global__ void k_lower_bounds(const uint32_t *__restrict__ keys, int n, Thresholds thr,
                                int nthr, int *__restrict__ out) {
     int t = threadIdx.x;

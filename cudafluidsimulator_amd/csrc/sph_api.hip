@@ -460,6 +460,39 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
     return SPH_OK;
 }
 
+int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
+                       const uint32_t *thresholds, int nthr, int32_t *bounds_out) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, src_buf, 0, 0, 0);
+    if (rc) return rc;
+    if (src_offset < 0 || count < 0 || (long long)src_offset + count > h->cap || nthr < 1 ||
+        nthr > 8 || !thresholds || !bounds_out)
+        return fail(h, SPH_EINVAL, "bad partition range");
+    for (int k = 1; k < nthr; ++k)
+        if (thresholds[k] < thresholds[k - 1]) return fail(h, SPH_EINVAL, "thresholds must ascend");
+    hipStream_t s = h->compute;
+    PairEvent *pe = nullptr;
+    if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
+    Thresholds T{};
+    for (int k = 0; k < nthr; ++k) T.v[k] = thresholds[k];
+    sph_launch_classify(h->P, h->pos4[src_buf] + src_offset, T, nthr, h->ws.keys[0], h->ws.vals[0],
+                        count, s);
+    int res = sph_sort_pairs(h->ws, count, 4, s); // classes 0..8: one radix pass, stable
+    sph_launch_gather_plain(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
+                            h->ws.vals[res], h->pos4[src_buf ^ 1], h->vel4[src_buf ^ 1], count, s);
+    HIPCHK(h, hipEventRecord(pe->b, s));
+    // bounds[k] = #particles with key < thresholds[k] = #classes <= k
+    Thresholds C{};
+    for (int k = 0; k < nthr; ++k) C.v[k] = (uint32_t)(k + 1);
+    sph_launch_lower_bounds(h->ws.keys[res], count, C, nthr, h->boundsDev, s);
+    HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
+    HIPCHK(h, hipGetLastError());
+    h->gridValid = false; // no cell table: sph_slab_sort builds it for the combined array
+    return SPH_OK;
+}
+
 int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     if (!h) return SPH_EINVAL;
     int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);

@@ -68,6 +68,10 @@ void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
 struct Thresholds { uint32_t v[8]; };
 void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr, int nthr,
                              int *bounds_dev, hipStream_t s);
+void sph_launch_classify(const DevParams &P, const float4 *pos4, Thresholds thr, int nthr,
+                         uint32_t *keys, uint32_t *vals, int n, hipStream_t s);
+void sph_launch_gather_plain(const float4 *pos_in, const float4 *vel_in, const uint32_t *perm,
+                             float4 *pos_out, float4 *vel_out, int n, hipStream_t s);
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4,
                       int mx, int my, hipStream_t s);
 

@@ -118,6 +118,13 @@ class HipSlabBackend:
                     "sph_slab_sort")
         return list(out)
 
+    def partition(self, src_buf, offset, count, thresholds):
+        thr = (C.c_uint32 * len(thresholds))(*[int(t) for t in thresholds])
+        out = (C.c_int32 * len(thresholds))()
+        self._check(self._L.sph_slab_partition(self._h, src_buf, offset, count, thr, len(thresholds),
+                                               out), "sph_slab_partition")
+        return list(out)
+
     def density(self, buf, i0, i1, n_all):
         self._check(self._L.sph_slab_density(self._h, buf, i0, i1, n_all), "sph_slab_density")
 
@@ -168,10 +175,14 @@ class Slab:
         a, b = self.off, self.off + self.n_own
         return self.b.pos[self.cur][a:b], self.b.vel[self.cur][a:b]
 
-    # ---- phase 1: local sort; returns the counts both neighbours need ----
+    # ---- phase 1: split the owned particles into [migrants down | lower boundary
+    # layer | interior | upper boundary layer | migrants up] by their NEW cell,
+    # previous order kept inside each part (a stable partition, not a sort: the
+    # combined array is sorted by key afterwards, and a stable sort of it only
+    # needs the right order among EQUAL keys).  Returns the counts both neighbours need.
     def local_sort(self):
         n = self.n_own
-        b0, b1, b2, b3 = self.b.sort(self.cur, self.off, n, self.thr)
+        b0, b1, b2, b3 = self.b.partition(self.cur, self.off, n, self.thr)
         if not self.has_dn:
             assert b0 == 0
         if not self.has_up:

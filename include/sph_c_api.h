@@ -186,6 +186,15 @@ int sph_bind_buffers(sph_handle *h, void *pos4_a, void *vel4_a, void *pos4_b,
  * (k < nthr <= 8); blocks until those counts are on the host. */
 int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
                   const uint32_t *thresholds, int nthr, int32_t *bounds_out);
+/* Stable PARTITION of particles [src_offset, src_offset+count) of buffer pair
+ * `src_buf` into [0, count) of the other pair by key class (class = number of
+ * thresholds <= the particle's new cell key; previous order kept inside a class).
+ * What a rank needs before the exchange: [migrants down | lower boundary layer |
+ * interior | upper boundary layer | migrants up] as contiguous ranges, at a third of
+ * the launches of a full sort.  bounds_out[k] = number of particles with key <
+ * thresholds[k].  Builds no cell table (sph_slab_sort of the combined array does). */
+int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
+                       const uint32_t *thresholds, int nthr, int32_t *bounds_out);
 /* kernelUpdatePressureAndDensity for particles [i_begin, i_end) of the n_all
  * sorted particles in buffer pair `buf` (halo particles are candidates only). */
 int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all);

@@ -29,6 +29,18 @@ class OracleSlabBackend:
         self.cs, self.ce = O.cell_table(sk, self.num_cells)
         return [int(np.searchsorted(sk, t, side="left")) for t in thresholds]
 
+    def partition(self, src_buf, offset, count, thresholds):
+        P, V = self.pos[src_buf].numpy(), self.vel[src_buf].numpy()
+        p = P[offset:offset + count].copy()
+        v = V[offset:offset + count].copy()
+        keys = O.cell_keys(self.settings, np.ascontiguousarray(p[:, :3]))
+        cls = np.searchsorted(np.asarray(thresholds, dtype=np.uint32), keys, side="right")
+        perm = np.argsort(cls, kind="stable")
+        self.pos[src_buf ^ 1].numpy()[:count] = p[perm]
+        self.vel[src_buf ^ 1].numpy()[:count] = v[perm]
+        self.cs = self.ce = None
+        return [int((cls <= k).sum()) for k in range(len(thresholds))]
+
     def density(self, buf, i0, i1, n_all):
         pos = np.ascontiguousarray(self.pos[buf].numpy()[:n_all, :3])
         rho, _ = O.density(self.settings, pos, self.cs, self.ce, i0, i1)
