@@ -112,6 +112,11 @@ def load_traffic(n, args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): whatever libraries print on file
+    # descriptor 1 (the RCCL start-up banner, gloo connection notes) goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -292,7 +297,8 @@ def main():
             out["debug_stamps"] = result["stamps"]
         if args.cpu_steps > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_particles or n, random_init, args.cpu_steps)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if world > 1:
         dist.barrier()

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sph_download_force", "sph_download_grid", "sph_sync", "sph_num_particles",
     "sph_get_kernel_times", "sph_last_error", "sph_phase_grid", "sph_phase_density",
     "sph_phase_force", "sph_phase_readback", "sph_sort_check", "sph_build_info",
-    "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_partition", "sph_slab_density",
+    "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_partition", "sph_slab_copy_segments", "sph_slab_density",
     "sph_slab_force", "sph_initial_positions", "sph_save_state", "sph_load_state",
     "sph_debug_counters",
 ]
@@ -106,7 +106,9 @@ def load_library():
     L.sph_set_stream.argtypes = [hp, C.c_void_p]
     L.sph_bind_buffers.argtypes = [hp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.sph_slab_sort.argtypes = [hp, C.c_int, C.c_int, C.c_int, u32p, C.c_int, i32p]
-    L.sph_slab_partition.argtypes = [hp, C.c_int, C.c_int, C.c_int, u32p, C.c_int, i32p]
+    L.sph_slab_copy_segments.argtypes = [hp, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         i32p, i32p]
+    L.sph_slab_partition.argtypes = [hp, C.c_int, C.c_int, C.c_int, u32p, C.c_int, i32p, C.c_void_p]
     L.sph_slab_density.argtypes = [hp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.sph_slab_force.argtypes = [hp, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L

@@ -128,9 +128,31 @@ void sph_launch_gather_plain(const float4 *pos_in, const float4 *vel_in, const u
     k_gather_plain<<<(n + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, pos_out, vel_out, n);
 }
 
+// Assembly of a slab's combined array: up to 8 (pos4, vel4) row ranges copied to their
+// places in ONE launch (they are small -- a boundary layer, a handful of migrants --
+// and fourteen separate copies were launch-bound).
+__global__ __launch_bounds__(256) void k_copy_segments(SegmentTable T, float4 *__restrict__ dpos,
+                                                       float4 *__restrict__ dvel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.prefix[T.n]) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) k += (q < T.n && i >= T.prefix[q]) ? 1 : 0;
+    const int r = i - T.prefix[k];
+    dpos[T.dst[k] + r] = T.spos[k][r];
+    dvel[T.dst[k] + r] = T.svel[k][r];
+}
+
+void sph_launch_copy_segments(const SegmentTable &T, float4 *dpos, float4 *dvel, hipStream_t s) {
+    const int total = T.prefix[T.n];
+    if (total <= 0) return;
+    k_copy_segments<<<(total + 255) / 256, 256, 0, s>>>(T, dpos, dvel);
+}
+
 __global__ void k_lower_bounds(const uint32_t *__restrict__ keys, int n, Thresholds thr,
                                int nthr, int *__restrict__ out) {
     int t = threadIdx.x;
+    if (t == nthr) out[nthr] = n; // the element count rides along (slab message headers)
     if (t >= nthr) return;
     uint32_t v = thr.v[t];
     int lo = 0, hi = n; // first index with keys[idx] >= v

@@ -233,7 +233,7 @@ int alloc_device(sph_handle *h) {
         HIPCHK(h, hipMalloc(&h->maskCursor, sizeof(unsigned long long)));
         HIPCHK(h, hipMemset(h->maskCursor, 0, sizeof(unsigned long long)));
     }
-    HIPCHK(h, hipMalloc(&h->boundsDev, 8 * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->boundsDev, 16 * sizeof(int)));
     HIPCHK(h, hipHostMalloc(&h->boundsHost, 8 * sizeof(int), hipHostMallocDefault));
     for (auto &pe : h->pairs) {
         HIPCHK(h, hipEventCreate(&pe.a));
@@ -461,7 +461,8 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
 }
 
 int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
-                       const uint32_t *thresholds, int nthr, int32_t *bounds_out) {
+                       const uint32_t *thresholds, int nthr, int32_t *bounds_out,
+                       void *bounds_dev_out) {
     if (!h) return SPH_EINVAL;
     int rc = slab_range_ok(h, src_buf, 0, 0, 0);
     if (rc) return rc;
@@ -484,12 +485,40 @@ int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
     // bounds[k] = #particles with key < thresholds[k] = #classes <= k
     Thresholds C{};
     for (int k = 0; k < nthr; ++k) C.v[k] = (uint32_t)(k + 1);
-    sph_launch_lower_bounds(h->ws.keys[res], count, C, nthr, h->boundsDev, s);
+    sph_launch_lower_bounds(h->ws.keys[res], count, C, nthr, h->boundsDev, s); // also [nthr] = count
+    if (bounds_dev_out) // the message header of the exchange, without a trip through the host
+        HIPCHK(h, hipMemcpyAsync(bounds_dev_out, h->boundsDev, (nthr + 1) * sizeof(int),
+                                 hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
     HIPCHK(h, hipGetLastError());
     h->gridValid = false; // no cell table: sph_slab_sort builds it for the combined array
+    return SPH_OK;
+}
+
+int sph_slab_copy_segments(sph_handle *h, int dst_buf, int nseg, const void *const *src_pos,
+                           const void *const *src_vel, const int32_t *counts,
+                           const int32_t *dst_offsets) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, dst_buf, 0, 0, 0);
+    if (rc) return rc;
+    if (nseg < 0 || nseg > 8 || (nseg > 0 && (!src_pos || !src_vel || !counts || !dst_offsets)))
+        return fail(h, SPH_EINVAL, "bad segment list");
+    SegmentTable T{};
+    T.n = nseg;
+    T.prefix[0] = 0;
+    for (int k = 0; k < nseg; ++k) {
+        if (counts[k] < 0 || dst_offsets[k] < 0 || (long long)dst_offsets[k] + counts[k] > h->cap ||
+            (counts[k] > 0 && (!src_pos[k] || !src_vel[k])))
+            return fail(h, SPH_EINVAL, "segment outside the bound buffers");
+        T.spos[k] = static_cast<const float4 *>(src_pos[k]);
+        T.svel[k] = static_cast<const float4 *>(src_vel[k]);
+        T.dst[k] = dst_offsets[k];
+        T.prefix[k + 1] = T.prefix[k] + counts[k];
+    }
+    sph_launch_copy_segments(T, h->pos4[dst_buf], h->vel4[dst_buf], h->compute);
+    HIPCHK(h, hipGetLastError());
     return SPH_OK;
 }
 

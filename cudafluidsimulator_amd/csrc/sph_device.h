@@ -72,6 +72,14 @@ void sph_launch_classify(const DevParams &P, const float4 *pos4, Thresholds thr,
                          uint32_t *keys, uint32_t *vals, int n, hipStream_t s);
 void sph_launch_gather_plain(const float4 *pos_in, const float4 *vel_in, const uint32_t *perm,
                              float4 *pos_out, float4 *vel_out, int n, hipStream_t s);
+struct SegmentTable {
+    const float4 *spos[8];
+    const float4 *svel[8];
+    int dst[8];
+    int prefix[9]; // rows before segment k; prefix[n] = total
+    int n;
+};
+void sph_launch_copy_segments(const SegmentTable &T, float4 *dpos, float4 *dvel, hipStream_t s);
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4,
                       int mx, int my, hipStream_t s);
 

@@ -8,11 +8,16 @@ are contiguous too.  Support radius = cell size, so the halo is ONE layer.
 
 Per step and rank (buffers: pos4[2], vel4[2]; `s` sorted, `t` the other pair):
 
-  1. sort own particles by cell key            -> [mig_dn|bnd_lo|interior|bnd_hi|mig_up]
-  2. exchange counts, then (RCCL send/recv)    : migrants (pos+vel) and boundary
-                                                 layers (pos+vel) to both neighbours
-  3. assemble t = [H_lo | my mig_dn | R_lo | stay | R_hi | my mig_up | H_hi]
-     and sort it again (stable)                -> [halo_lo | owned | halo_hi] + cell table
+  1. stable partition of own particles by the
+     segment their NEW cell key falls in       -> [mig_dn|bnd_lo|interior|bnd_hi|mig_up]
+  2. exchange A (RCCL send/recv, ONE round)    : to each neighbour a header (the partition
+                                                 bounds, written on the device) and a FIXED
+                                                 number of rows holding migrants + boundary
+                                                 layer (pos, vel) -- no count exchange first;
+                                                 a face that outgrows the fixed size sends
+                                                 the rest in a second, exact-size round
+  3. assemble t = [H_lo | my mig_dn | from below | mine | from above | my mig_up | H_hi]
+     and sort it (stable, by cell key)         -> [halo_lo | owned | halo_hi] + cell table
   4. density for owned; exchange vel4 (carries rho) of the boundary layers
   5. force + integrate for owned               -> new owned state in t
 
@@ -118,12 +123,29 @@ class HipSlabBackend:
                     "sph_slab_sort")
         return list(out)
 
-    def partition(self, src_buf, offset, count, thresholds):
+    def partition(self, src_buf, offset, count, thresholds, hdr=None):
+        """hdr: int32 device tensor (>= len(thresholds)+1) that receives the bounds and
+        `count` on the device, stream-ordered (the exchange's message header)."""
         thr = (C.c_uint32 * len(thresholds))(*[int(t) for t in thresholds])
         out = (C.c_int32 * len(thresholds))()
         self._check(self._L.sph_slab_partition(self._h, src_buf, offset, count, thr, len(thresholds),
-                                               out), "sph_slab_partition")
+                                               out, C.c_void_p(hdr.data_ptr()) if hdr is not None else None),
+                    "sph_slab_partition")
         return list(out)
+
+    def copy_segments(self, dst_buf, pieces):
+        """pieces: [(pos rows, vel rows, first destination row)] -> rows of pair dst_buf,
+        eight pieces per kernel launch."""
+        pieces = [p for p in pieces if len(p[0])]
+        for a in range(0, len(pieces), 8):
+            chunk = pieces[a:a + 8]
+            k = len(chunk)
+            sp = (C.c_void_p * k)(*[p[0].data_ptr() for p in chunk])
+            sv = (C.c_void_p * k)(*[p[1].data_ptr() for p in chunk])
+            cnt = (C.c_int32 * k)(*[len(p[0]) for p in chunk])
+            dst = (C.c_int32 * k)(*[int(p[2]) for p in chunk])
+            self._check(self._L.sph_slab_copy_segments(self._h, dst_buf, k, sp, sv, cnt, dst),
+                        "sph_slab_copy_segments")
 
     def density(self, buf, i0, i1, n_all):
         self._check(self._L.sph_slab_density(self._h, buf, i0, i1, n_all), "sph_slab_density")
@@ -148,7 +170,14 @@ DOWN, UP = -1, +1
 
 
 class Slab:
-    def __init__(self, backend, rank, world, zlo, zhi, D):
+    """One rank's slab.  `face_cap` (rows) is the fixed size of an exchange-A message
+    per face; it MUST be the same on every rank (default: capacity // 4 of equally
+    sized backends).  A face that needs more sends the excess in a second, exact-size
+    message, so the value only affects speed."""
+
+    HDR = 8  # int32 per message header: b0, b1, b2, b3, n (+ padding)
+
+    def __init__(self, backend, rank, world, zlo, zhi, D, face_cap=None):
         self.b = backend
         self.rank, self.world = rank, world
         self.zlo, self.zhi, self.D = zlo, zhi, D
@@ -160,6 +189,16 @@ class Slab:
         self.cur, self.off, self.n_own = 0, 0, 0
         self.seg = None
         self.steps = 0
+        self.F = int(face_cap) if face_cap is not None else max(1, backend.cap // 4)
+        if self.F > backend.cap:
+            raise ValueError("face_cap exceeds the slab capacity")
+        dev = backend.device
+        self.hdr_tx = torch.zeros(self.HDR, dtype=torch.int32, device=dev)
+        self.hdr_rx = torch.zeros((2, self.HDR), dtype=torch.int32, device=dev)  # [from dn, from up]
+        # landing areas of the fixed-size messages: [0] from below, [1] from above
+        self.rx_pos = [torch.zeros((self.F, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.rx_vel = [torch.zeros((self.F, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.overflows = 0
 
     # ---- initial state: owned particles in particle-id order ----
     def load(self, pos4, vel4):
@@ -179,28 +218,127 @@ class Slab:
     # layer | interior | upper boundary layer | migrants up] by their NEW cell,
     # previous order kept inside each part (a stable partition, not a sort: the
     # combined array is sorted by key afterwards, and a stable sort of it only
-    # needs the right order among EQUAL keys).  Returns the counts both neighbours need.
+    # needs the right order among EQUAL keys).  The bounds land in hdr_tx on the device.
     def local_sort(self):
         n = self.n_own
-        b0, b1, b2, b3 = self.b.partition(self.cur, self.off, n, self.thr)
+        b0, b1, b2, b3 = self.b.partition(self.cur, self.off, n, self.thr, self.hdr_tx)
         if not self.has_dn:
             assert b0 == 0
         if not self.has_up:
             assert b3 == n
         self.s = self.cur ^ 1
         self.seg = (b0, b1, b2, b3, n)
-        to_dn = [b0, b1 - b0] if self.has_dn else None      # [migrants, boundary layer]
-        to_up = [n - b3, b3 - b2] if self.has_up else None
-        return to_dn, to_up
 
-    # ---- phase 2: plan exchange A given the neighbours' counts ----
-    def plan_exchange_a(self, from_dn, from_up):
+    # Where a message's payload sits.  DOWN message = [migrants down | lower boundary]
+    # = rows [0, b1) of the sender's partitioned array; the window sent is rows [0, F).
+    # UP message = [upper boundary | migrants up] = rows [b2, n); the window is the LAST
+    # F rows, [n-F, n) (rows [0, F) if n < F).  Anything that does not fit the window
+    # goes in a second message ("extra").  Both ends compute this from (b0..b3, n).
+    def _down_layout(self, b0, b1, b2, b3, n):
+        payload = b1
+        extra = max(0, payload - self.F)           # rows [F, b1) of the sender
+        return payload, 0, extra                   # payload, offset in window, rows in the extra message
+
+    def _up_layout(self, b0, b1, b2, b3, n):
+        payload = n - b2
+        extra = max(0, payload - self.F)           # rows [b2, n-F) of the sender: the FIRST rows
+        if extra:
+            return payload, 0, extra
+        return payload, (self.F - payload) if n >= self.F else b2, 0
+
+    # ---- phase 2: post exchange A (fixed sizes: no count exchange beforehand) ----
+    def plan_exchange_a(self):
         b0, b1, b2, b3, n = self.seg
-        mig_from_dn, bnd_from_dn = from_dn if self.has_dn else (0, 0)
-        mig_from_up, bnd_from_up = from_up if self.has_up else (0, 0)
-        s, t = self.s, self.s ^ 1
+        s = self.s
         P, V = self.b.pos, self.b.vel
-        # t = [H_lo | my mig_dn | R_lo | stay | R_hi | my mig_up | H_hi]
+        F = self.F
+        sends, recvs = [], []
+        if self.has_dn:
+            sends += [(DOWN, self.hdr_tx), (DOWN, P[s][0:F]), (DOWN, V[s][0:F])]
+            recvs += [(DOWN, self.hdr_rx[0]), (DOWN, self.rx_pos[0]), (DOWN, self.rx_vel[0])]
+        if self.has_up:
+            w0 = max(n - F, 0)
+            sends += [(UP, self.hdr_tx), (UP, P[s][w0:w0 + F]), (UP, V[s][w0:w0 + F])]
+            recvs += [(UP, self.hdr_rx[1]), (UP, self.rx_pos[1]), (UP, self.rx_vel[1])]
+        return sends, recvs
+
+    # ---- phase 2b: read the neighbours' headers; plan the (rare) overflow messages ----
+    def plan_overflow(self):
+        b0, b1, b2, b3, n = self.seg
+        s = self.s
+        P, V = self.b.pos, self.b.vel
+        F = self.F
+        hdr = self.hdr_rx.tolist() if (self.has_dn or self.has_up) else [[0] * self.HDR] * 2
+        self.nb_dn = tuple(hdr[0][:5]) if self.has_dn else None   # neighbour below: its UP message
+        self.nb_up = tuple(hdr[1][:5]) if self.has_up else None   # neighbour above: its DOWN message
+        sends, recvs = [], []
+        self.extra_rx = [None, None]
+        # my own excess rows
+        if self.has_dn:
+            _, _, ex = self._down_layout(b0, b1, b2, b3, n)
+            if ex:
+                sends += [(DOWN, P[s][F:b1]), (DOWN, V[s][F:b1])]
+        if self.has_up:
+            _, _, ex = self._up_layout(b0, b1, b2, b3, n)
+            if ex:
+                sends += [(UP, P[s][b2:b2 + ex]), (UP, V[s][b2:b2 + ex])]
+        # the neighbours' excess rows
+        dev = self.b.device
+        if self.has_dn:
+            _, _, ex = self._up_layout(*self.nb_dn)
+            if ex:
+                self.extra_rx[0] = (torch.empty((ex, 4), dtype=torch.float32, device=dev),
+                                    torch.empty((ex, 4), dtype=torch.float32, device=dev))
+                recvs += [(DOWN, self.extra_rx[0][0]), (DOWN, self.extra_rx[0][1])]
+        if self.has_up:
+            _, _, ex = self._down_layout(*self.nb_up)
+            if ex:
+                self.extra_rx[1] = (torch.empty((ex, 4), dtype=torch.float32, device=dev),
+                                    torch.empty((ex, 4), dtype=torch.float32, device=dev))
+                recvs += [(UP, self.extra_rx[1][0]), (UP, self.extra_rx[1][1])]
+        if sends or recvs:
+            self.overflows += 1
+        return sends, recvs
+
+    def _payload_rows(self, which, kind, a, b):
+        """Pieces (tensor views) holding payload rows [a, b) of the message received
+        from below (which=0: an UP message) or above (which=1: a DOWN message)."""
+        if b <= a:
+            return []
+        rx = (self.rx_pos if kind == 0 else self.rx_vel)[which]
+        if which == 0:
+            payload, off, ex = self._up_layout(*self.nb_dn)
+        else:
+            payload, off, ex = self._down_layout(*self.nb_up)
+        pieces = []
+        if which == 0:      # UP message: the extra rows come FIRST, the window holds the rest
+            if a < ex:
+                pieces.append(self.extra_rx[0][kind][a:min(b, ex)])
+            if b > ex:
+                lo = max(a, ex) - ex
+                pieces.append(rx[off + lo: off + (b - ex)])
+        else:               # DOWN message: the window holds rows [0, F), the extra rows follow
+            inwin = payload - ex
+            if a < inwin:
+                pieces.append(rx[off + a: off + min(b, inwin)])
+            if b > inwin:
+                pieces.append(self.extra_rx[1][kind][max(a, inwin) - inwin: b - inwin])
+        return pieces
+
+    # ---- phase 2c: assemble t = [H_lo | my mig_dn | from below | mine | from above | my mig_up | H_hi]
+    def assemble(self):
+        b0, b1, b2, b3, n = self.seg
+        if self.has_dn:
+            _, _, nb2, nb3, nn = self.nb_dn
+            bnd_from_dn, mig_from_dn = nb3 - nb2, nn - nb3
+        else:
+            bnd_from_dn = mig_from_dn = 0
+        if self.has_up:
+            ub0, ub1 = self.nb_up[0], self.nb_up[1]
+            mig_from_up, bnd_from_up = ub0, ub1 - ub0
+        else:
+            mig_from_up = bnd_from_up = 0
+        s, t = self.s, self.s ^ 1
         o = [0]
         for c in (bnd_from_dn, b0, mig_from_dn, b3 - b0, mig_from_up, n - b3, bnd_from_up):
             o.append(o[-1] + c)
@@ -209,33 +347,25 @@ class Slab:
             raise SphError("slab capacity exceeded by halo + migrants")
         self.halo_lo_expected = bnd_from_dn + b0
         self.halo_hi_expected = bnd_from_up + (n - b3)
-        for A in (P, V):
-            if b0:
-                A[t][o[1]:o[2]].copy_(A[s][0:b0])
-            if b3 - b0:
-                A[t][o[3]:o[4]].copy_(A[s][b0:b3])
-            if n - b3:
-                A[t][o[5]:o[6]].copy_(A[s][b3:n])
-        sends, recvs = [], []
-        if self.has_dn:   # message order (both sides): boundary layer first, then migrants
-            for A in (P, V):
-                sends.append((DOWN, A[s][b0:b1]))
-            for A in (P, V):
-                sends.append((DOWN, A[s][0:b0]))
-            for A in (P, V):
-                recvs.append((DOWN, A[t][o[0]:o[1]]))
-            for A in (P, V):
-                recvs.append((DOWN, A[t][o[2]:o[3]]))
-        if self.has_up:
-            for A in (P, V):
-                sends.append((UP, A[s][b2:b3]))
-            for A in (P, V):
-                sends.append((UP, A[s][b3:n]))
-            for A in (P, V):
-                recvs.append((UP, A[t][o[6]:o[7]]))
-            for A in (P, V):
-                recvs.append((UP, A[t][o[4]:o[5]]))
-        return sends, recvs
+        P, V = self.b.pos, self.b.vel
+        pieces = [(P[s][0:b0], V[s][0:b0], o[1]),          # my migrants down
+                  (P[s][b0:b3], V[s][b0:b3], o[3]),        # what stays mine
+                  (P[s][b3:n], V[s][b3:n], o[5])]          # my migrants up
+
+        def put(dst0, which, a, b):
+            at = dst0
+            for pp, vv in zip(self._payload_rows(which, 0, a, b), self._payload_rows(which, 1, a, b)):
+                pieces.append((pp, vv, at))
+                at += len(pp)
+            assert at == dst0 + max(b - a, 0)
+
+        # from below: [its upper boundary | its migrants up]
+        put(o[0], 0, 0, bnd_from_dn)
+        put(o[2], 0, bnd_from_dn, bnd_from_dn + mig_from_dn)
+        # from above: [its migrants down | its lower boundary]
+        put(o[4], 1, 0, mig_from_up)
+        put(o[6], 1, mig_from_up, mig_from_up + bnd_from_up)
+        self.b.copy_segments(t, pieces)
 
     # ---- phase 3: sort the combined array, density, plan exchange B ----
     def combined_sort_and_density(self):
@@ -284,25 +414,6 @@ class DistTransport:
         # point-to-point).  Only for rehearsing the multi-rank path on ONE GPU.
         self.via_cpu = via_cpu
 
-    def exchange_counts(self, to_dn, to_up):
-        dist = self.dist
-        ops, bufs = [], {}
-        for d, payload in ((DOWN, to_dn), (UP, to_up)):
-            if payload is None:
-                continue
-            peer = self.rank + d
-            cdev = "cpu" if self.via_cpu else self.device
-            snd = torch.tensor(payload, dtype=torch.int64, device=cdev)
-            rcv = torch.zeros(len(payload), dtype=torch.int64, device=cdev)
-            bufs[d] = (snd, rcv)
-            ops.append(dist.P2POp(dist.isend, snd, peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, rcv, peer, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        out = {d: bufs[d][1].tolist() for d in bufs}
-        return out.get(DOWN), out.get(UP)
-
     def exchange(self, sends, recvs):
         dist = self.dist
         ops, landing = [], []
@@ -322,15 +433,15 @@ class DistTransport:
 
 
 def step_distributed(slab, tr):
-    """One step of this rank's slab over a DistTransport."""
-    to_dn, to_up = slab.local_sort()
-    from_dn, from_up = tr.exchange_counts(to_dn, to_up)
-    # a neighbour sends [migrants, boundary]; from below the migrants are its
-    # mig_up / boundary its bnd_hi, from above its mig_dn / bnd_lo
-    sends, recvs = slab.plan_exchange_a(from_dn, from_up)
-    tr.exchange(sends, recvs)
-    sends, recvs = slab.combined_sort_and_density()
-    tr.exchange(sends, recvs)
+    """One step of this rank's slab over a DistTransport: two message rounds (A:
+    particles, B: densities); a third only when a face outgrew its fixed-size message."""
+    slab.local_sort()
+    tr.exchange(*slab.plan_exchange_a())
+    sends, recvs = slab.plan_overflow()
+    if sends or recvs:
+        tr.exchange(sends, recvs)
+    slab.assemble()
+    tr.exchange(*slab.combined_sort_and_density())
     slab.force()
 
 
@@ -378,13 +489,15 @@ def run_loopback(slabs, steps, copy=None):
                 dst.copy_(src)
 
     for _ in range(steps):
-        counts = [s.local_sort() for s in slabs]
-        plans = []
-        for r, s in enumerate(slabs):
-            from_dn = counts[r - 1][1] if r > 0 else None
-            from_up = counts[r + 1][0] if r + 1 < len(slabs) else None
-            plans.append(s.plan_exchange_a(from_dn, from_up))
+        for s in slabs:
+            s.local_sort()
+        plans = [s.plan_exchange_a() for s in slabs]
         deliver([p[0] for p in plans], [p[1] for p in plans])
+        plans = [s.plan_overflow() for s in slabs]
+        if any(p[0] or p[1] for p in plans):
+            deliver([p[0] for p in plans], [p[1] for p in plans])
+        for s in slabs:
+            s.assemble()
         plans = [s.combined_sort_and_density() for s in slabs]
         deliver([p[0] for p in plans], [p[1] for p in plans])
         for s in slabs:
@@ -428,6 +541,13 @@ def split_initial(pos4, vel4, h, D, world):
     return bounds, parts
 
 
+def default_face_cap(pos4, h, D):
+    """Rows per fixed-size exchange-A message: 1.25 x the fullest z-layer (one boundary
+    layer plus the step's migrants; a fuller face falls back to a second message)."""
+    hist = np.bincount(layer_of(pos4[:, 2], h, D), minlength=D)
+    return int(1.25 * int(hist.max())) + 4096
+
+
 def run_slab_bench(args, dist, rank, world, local_rank):
     """bench.py's N>1 leg: strong scaling of one n-particle domain over `world`
     GPUs.  Returns rank-local timing; bench.py takes the max over ranks."""
@@ -442,9 +562,17 @@ def run_slab_bench(args, dist, rank, world, local_rank):
     cap = int(max(len(p[0]) for p in parts) * 1.6) + 65536
     backend = HipSlabBackend(settings, cap, device=local_rank, sweep=args.sweep,
                              flags=_lib.SPH_FLAG_COUNT_PAIRS)
-    slab = Slab(backend, rank, world, zlo, zhi, D)
+    slab = Slab(backend, rank, world, zlo, zhi, D, face_cap=min(default_face_cap(pos4, settings.h, D), cap))
     tr = DistTransport(dist, rank, world, backend.device, via_cpu=dist.get_backend() == "gloo")
+    # Per-step position read-back (simulator.cu:479) of the owned particles, off the
+    # compute stream like the single-domain path: a device-side snapshot (a few
+    # microseconds) and then the PCIe copy on its own stream, double-buffered, so step
+    # k+1 computes while step k's positions travel.
     host = torch.empty((cap, 4), dtype=torch.float32).pin_memory()
+    snap = [torch.empty((cap, 4), dtype=torch.float32, device=backend.device) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=backend.device)
+    snap_free = [None, None]   # event: the D2H copy out of snap[i] has finished
+    counter = [0]
 
     def reload():
         slab.load(torch.from_numpy(my_pos).to(backend.device), torch.from_numpy(my_vel).to(backend.device))
@@ -452,7 +580,19 @@ def run_slab_bench(args, dist, rank, world, local_rank):
     def one_step():
         step_distributed(slab, tr)
         p, _ = slab.owned()
-        host[:len(p)].copy_(p, non_blocking=True)   # per-step position read-back (simulator.cu:479)
+        i = counter[0] & 1
+        counter[0] += 1
+        cur = torch.cuda.current_stream(backend.device)
+        if snap_free[i] is not None:
+            cur.wait_event(snap_free[i])
+        snap[i][:len(p)].copy_(p)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        copy_stream.wait_event(ready)
+        with torch.cuda.stream(copy_stream):
+            host[:len(p)].copy_(snap[i][:len(p)], non_blocking=True)
+            snap_free[i] = torch.cuda.Event()
+            snap_free[i].record(copy_stream)
 
     reload()
     # at least one untimed step: the first P2P call builds the RCCL communicators
@@ -471,4 +611,4 @@ def run_slab_bench(args, dist, rank, world, local_rank):
     kt = backend.kernel_times()
     n_local = slab.n_own
     backend.close()
-    return dict(elapsed=elapsed, kt=kt, n_total=n, n_local=n_local)
+    return dict(elapsed=elapsed, kt=kt, n_total=n, n_local=n_local, overflow_rounds=slab.overflows)

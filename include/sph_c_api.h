@@ -192,9 +192,20 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
  * What a rank needs before the exchange: [migrants down | lower boundary layer |
  * interior | upper boundary layer | migrants up] as contiguous ranges, at a third of
  * the launches of a full sort.  bounds_out[k] = number of particles with key <
- * thresholds[k].  Builds no cell table (sph_slab_sort of the combined array does). */
+ * thresholds[k].  Builds no cell table (sph_slab_sort of the combined array does).
+ * bounds_dev_out (may be NULL): DEVICE pointer that receives nthr+1 int32 -- the
+ * bounds, then `count` -- stream-ordered, so the driver can send them to the
+ * neighbours as a message header without a round trip through the host. */
 int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
-                       const uint32_t *thresholds, int nthr, int32_t *bounds_out);
+                       const uint32_t *thresholds, int nthr, int32_t *bounds_out,
+                       void *bounds_dev_out);
+/* Assemble the combined array: copy nseg <= 8 row ranges -- src_pos[k]/src_vel[k] are
+ * DEVICE pointers to counts[k] float4 rows each (ranges of the bound buffers or of the
+ * driver's receive buffers) -- to rows dst_offsets[k].. of buffer pair `dst_buf`, in one
+ * kernel launch on the handle's stream. */
+int sph_slab_copy_segments(sph_handle *h, int dst_buf, int nseg, const void *const *src_pos,
+                           const void *const *src_vel, const int32_t *counts,
+                           const int32_t *dst_offsets);
 /* kernelUpdatePressureAndDensity for particles [i_begin, i_end) of the n_all
  * sorted particles in buffer pair `buf` (halo particles are candidates only). */
 int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all);

@@ -23,7 +23,8 @@ for world in a.slabs:
     slabs = []
     for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
         cap = int(len(pp) * 1.5) + 65536
-        sl = S.Slab(S.HipSlabBackend(settings, cap, device=0), r, world, zlo, zhi, 100)
+        sl = S.Slab(S.HipSlabBackend(settings, cap, device=0), r, world, zlo, zhi, 100,
+                    face_cap=min(S.default_face_cap(p4, settings.h, 100), cap))
         sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
         slabs.append(sl)
     S.run_loopback(slabs, 2)

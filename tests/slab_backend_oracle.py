@@ -29,7 +29,7 @@ class OracleSlabBackend:
         self.cs, self.ce = O.cell_table(sk, self.num_cells)
         return [int(np.searchsorted(sk, t, side="left")) for t in thresholds]
 
-    def partition(self, src_buf, offset, count, thresholds):
+    def partition(self, src_buf, offset, count, thresholds, hdr=None):
         P, V = self.pos[src_buf].numpy(), self.vel[src_buf].numpy()
         p = P[offset:offset + count].copy()
         v = V[offset:offset + count].copy()
@@ -39,7 +39,16 @@ class OracleSlabBackend:
         self.pos[src_buf ^ 1].numpy()[:count] = p[perm]
         self.vel[src_buf ^ 1].numpy()[:count] = v[perm]
         self.cs = self.ce = None
-        return [int((cls <= k).sum()) for k in range(len(thresholds))]
+        bounds = [int((cls <= k).sum()) for k in range(len(thresholds))]
+        if hdr is not None:
+            hdr[:len(bounds) + 1] = torch.tensor(bounds + [count], dtype=torch.int32)
+        return bounds
+
+    def copy_segments(self, dst_buf, pieces):
+        for pp, vv, at in pieces:
+            if len(pp):
+                self.pos[dst_buf][at:at + len(pp)].copy_(pp)
+                self.vel[dst_buf][at:at + len(vv)].copy_(vv)
 
     def density(self, buf, i0, i1, n_all):
         pos = np.ascontiguousarray(self.pos[buf].numpy()[:n_all, :3])

@@ -63,8 +63,11 @@ def test_partition_layers():
     assert all(c - a >= 2 for a, c in b)
 
 
+@pytest.mark.parametrize("face_cap", [None, 5])
 @pytest.mark.parametrize("world", [2, 4])
-def test_loopback_slabs_equal_single_domain_cpu(world):
+def test_loopback_slabs_equal_single_domain_cpu(world, face_cap):
+    """face_cap=5: every face outgrows its fixed-size message, so the exact-size
+    overflow round carries most of the halo (both window layouts are exercised)."""
     n, steps = 6000, 12
     pos, vel = moving_state(n, 21)
     settings = sph.default_settings(n, False)
@@ -72,7 +75,7 @@ def test_loopback_slabs_equal_single_domain_cpu(world):
     bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
     slabs = []
     for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
-        sl = S.Slab(OracleSlabBackend(settings, n), r, world, zlo, zhi, 100)
+        sl = S.Slab(OracleSlabBackend(settings, n), r, world, zlo, zhi, 100, face_cap=face_cap)
         sl.load(torch.from_numpy(pp), torch.from_numpy(vv))
         slabs.append(sl)
     S.run_loopback(slabs, steps)
@@ -81,12 +84,13 @@ def test_loopback_slabs_equal_single_domain_cpu(world):
     assert_bit_equal(got[0], want["pos"], "pos")
     assert_bit_equal(got[1], want["vel"], "vel")
     assert_bit_equal(got[2], want["rho"], "rho")
+    assert (sum(sl.overflows for sl in slabs) > 0) == (face_cap is not None)
     # migration really happened
     assert sum(sl.n_own for sl in slabs) == n
     assert any(sl.n_own != len(parts[i][0]) for i, sl in enumerate(slabs))
 
 
-def _gloo_worker(rank, world, port, n, steps, seed, outdir):
+def _gloo_worker(rank, world, port, n, steps, seed, outdir, face_cap=None):
     import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
@@ -95,7 +99,7 @@ def _gloo_worker(rank, world, port, n, steps, seed, outdir):
     settings = sph.default_settings(n, False)
     p4, v4 = S.pack_state(pos, vel)
     bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
-    sl = S.Slab(OracleSlabBackend(settings, n), rank, world, *bounds[rank], 100)
+    sl = S.Slab(OracleSlabBackend(settings, n), rank, world, *bounds[rank], 100, face_cap=face_cap)
     sl.load(torch.from_numpy(parts[rank][0]), torch.from_numpy(parts[rank][1]))
     tr = S.DistTransport(dist, rank, world, torch.device("cpu"))
     for _ in range(steps):
@@ -106,12 +110,13 @@ def _gloo_worker(rank, world, port, n, steps, seed, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_slabs_equal_single_domain(world, tmp_path):
+@pytest.mark.parametrize("world,face_cap", [(2, None), (3, None), (3, 20)])
+def test_gloo_slabs_equal_single_domain(world, face_cap, tmp_path):
     import torch.multiprocessing as mp
     n, steps, seed = 4000, 10, 33
-    port = 29600 + world + (os.getpid() % 200)
-    mp.spawn(_gloo_worker, args=(world, port, n, steps, seed, str(tmp_path)), nprocs=world, join=True)
+    port = 29600 + world + (os.getpid() % 200) + (7 if face_cap else 0)
+    mp.spawn(_gloo_worker, args=(world, port, n, steps, seed, str(tmp_path), face_cap), nprocs=world,
+             join=True)
     parts = []
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
@@ -124,9 +129,9 @@ def test_gloo_slabs_equal_single_domain(world, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep", ["list", "lds"])
-@pytest.mark.parametrize("world", [2, 3])
-def test_hip_loopback_slabs_equal_single_domain(world, sweep):
+@pytest.mark.parametrize("world,sweep,face_cap", [(2, "list", None), (3, "list", None), (2, "lds", None),
+                                                  (3, "lds", None), (3, "list", 300)])
+def test_hip_loopback_slabs_equal_single_domain(world, sweep, face_cap):
     n, steps = 60000, 8
     pos, vel = moving_state(n, 5)
     settings = sph.default_settings(n, False)
@@ -134,7 +139,8 @@ def test_hip_loopback_slabs_equal_single_domain(world, sweep):
     bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
     slabs = []
     for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
-        sl = S.Slab(S.HipSlabBackend(settings, n, device=0, sweep=sweep), r, world, zlo, zhi, 100)
+        sl = S.Slab(S.HipSlabBackend(settings, n, device=0, sweep=sweep), r, world, zlo, zhi, 100,
+                    face_cap=face_cap)
         sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
         slabs.append(sl)
     S.run_loopback(slabs, steps)
@@ -143,6 +149,7 @@ def test_hip_loopback_slabs_equal_single_domain(world, sweep):
     assert_bit_equal(got[0], want["pos"], "pos")
     assert_bit_equal(got[1], want["vel"], "vel")
     assert_bit_equal(got[2], want["rho"], "rho")
+    assert (sum(sl.overflows for sl in slabs) > 0) == (face_cap is not None)
     # and against the single-domain HIP path
     sim = sph.Simulator(settings)
     sim.upload_state(pos, vel)
