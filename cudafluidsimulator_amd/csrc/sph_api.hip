@@ -219,9 +219,16 @@ int alloc_device(sph_handle *h) {
     if (h->opt.sweep == SPH_SWEEP_LIST) {
         // 128 dwords per particle slot = room for 64 (first candidate, mask) pairs,
         // i.e. 2048 candidates; the worst-case reservation measured at n = 4,194,304
-        // random is 32 dwords early and 74 at step 100.  A wave that finds the pool
-        // exhausted falls back to testing (sweeps_list.hip).
-        unsigned long long words = (unsigned long long)cap * 128ull;
+        // random is 32 dwords early and 74 at step 100.  Denser fills need more: the
+        // reservation is 2 dwords per 32 candidates plus up to 2 per run, candidates =
+        // 27 x particles per cell (about half the cells of the box hold particles with
+        // the reference initialisers), and it grows ~4x as the fluid settles.  A wave
+        // that finds the pool exhausted falls back to testing (sweeps_list.hip): at
+        // n = 16,777,216 that cost 7 % of the step with 128 dwords per slot.
+        const double ppc = (double)cap / (0.5 * (double)h->P.numCells);
+        const double est = 4.0 * (2.0 * 27.0 * ppc / 32.0 + 18.0);
+        unsigned long long perSlot = est > 128.0 ? (unsigned long long)est : 128ull;
+        unsigned long long words = (unsigned long long)cap * perSlot;
         if (words < (1ull << 22)) words = 1ull << 22;
         if (const char *e = getenv("SPH_MASK_POOL_WORDS")) words = strtoull(e, nullptr, 10);
         if (words > 0xFFFFFFF0ull) words = 0xFFFFFFF0ull; // offsets are 32-bit
