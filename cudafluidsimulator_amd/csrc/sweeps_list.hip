@@ -178,10 +178,31 @@ __global__ __launch_bounds__(SL_K1_THREADS) void k_density_mask_lds(DevParams P,
     };
     const int rowId = c.y + c.z * P.D;
     unsigned long long todo = __ballot(valid);
+    // Lanes are grouped by grid row only to keep a run's union inside the LDS slice:
+    // run ranges are monotone in the lane's cell key, so ANY set of lanes can share a
+    // staged range.  When the wave spans several rows but every run's union over all
+    // its lanes still fits (sparse fills: a thin sheet puts ~50 rows in one wave), one
+    // pass serves them all instead of one pass per row (n = 8192 -i grid: 0.33 -> 0.03 ms).
+    bool unify = false;
+    if (todo) {
+        const int row0 = __builtin_amdgcn_readlane(rowId, __ffsll((long long)todo) - 1);
+        if (__ballot(valid && rowId != row0)) {
+            unify = true;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const unsigned long long mm = __ballot(valid && je[r] > js[r]);
+                if (mm) {
+                    const int u0 = __builtin_amdgcn_readlane(js[r], __ffsll((long long)mm) - 1);
+                    const int u1 = __builtin_amdgcn_readlane(je[r], 63 - __clzll((long long)mm));
+                    unify = unify && (u1 - u0) <= SW_CAP;
+                }
+            }
+        }
+    }
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int rowL = __builtin_amdgcn_readlane(rowId, leader);
-        const bool act = valid && rowId == rowL;
+        const bool act = valid && (unify || rowId == rowL);
         todo &= ~__ballot(act);
 #pragma unroll 1
         for (int r = 0; r < 9; ++r) {
