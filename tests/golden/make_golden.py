@@ -4,7 +4,8 @@ The reference holds no golden vectors for this path and it
 source cannot run here, so these fixtures are ORACLE outputs: they pin the HIP
 path and the oracle to each other across rounds, not to the reference.  Data
 only: inputs are regenerated from seeds / the reference initialisers.
-Run:  python tests/golden/make_golden.py
+Run:  python tests/golden/make_golden.py          (the small array fixtures)
+      python tests/golden/make_golden.py --full   (sha256 of the n = 4,194,304 run)
 """
 import os
 import sys
@@ -54,7 +55,31 @@ def dense4096():
 
 CASES = {"grid2048": grid2048, "random4096": random4096, "dense4096": dense4096}
 
+
+def full_size_checksums(n=4194304, checkpoints=(1, 10, 30)):
+    """BASELINE config 3 (-n 4194304 -i random) is too big to commit as arrays: the
+    fixture is the sha256 of the oracle's position / density arrays (particle-id order,
+    raw fp32 bytes) at a few steps.  About two minutes of CPU."""
+    import hashlib
+    import json
+    sim = O.OracleSim(n, True)
+    sim.setup()
+    out = {"n": n, "init": "random", "order": "particle id", "dtype": "<f4", "steps": {}}
+    done = 0
+    for k in checkpoints:
+        sim.step(k - done)
+        done = k
+        d = sim.download()
+        out["steps"][str(k)] = {"pos_sha256": hashlib.sha256(np.ascontiguousarray(d["pos"]).tobytes()).hexdigest(),
+                                "rho_sha256": hashlib.sha256(np.ascontiguousarray(d["rho"]).tobytes()).hexdigest()}
+        print(n, k, out["steps"][str(k)], flush=True)
+    with open(os.path.join(HERE, f"random{n}_sha256.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
 if __name__ == "__main__":
+    if "--full" in sys.argv:
+        full_size_checksums()
+        sys.exit(0)
     for name, fn in CASES.items():
         out = fn()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

@@ -148,6 +148,29 @@ def test_coincident_particles_hit_eps_gates():
         sim.close()
 
 
+def test_headline_config_matches_the_oracles_checksums():
+    """BASELINE config 3 at FULL size (-n 4194304 -i random): sha256 of the raw fp32
+    position and density arrays (particle-id order) after 1, 10 and 30 steps against
+    the checksums the CPU oracle produced (tests/golden/make_golden.py --full)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(GOLD, "random4194304_sha256.json")))
+    sim = sph.Simulator(sph.default_settings(gold["n"], True))
+    sim.setup()
+    done = 0
+    for k in sorted(int(x) for x in gold["steps"]):
+        for _ in range(k - done):
+            sim.simulate()
+        done = k
+        st = sim.download_state()
+        want = gold["steps"][str(k)]
+        assert hashlib.sha256(np.ascontiguousarray(st["pos"]).tobytes()).hexdigest() == want["pos_sha256"], k
+        assert hashlib.sha256(np.ascontiguousarray(st["rho"]).tobytes()).hexdigest() == want["rho_sha256"], k
+        assert hashlib.sha256(np.ascontiguousarray(np.array(sim.getPosition())).tobytes()).hexdigest() == \
+            want["pos_sha256"], k
+    sim.close()
+
+
 @pytest.mark.parametrize("name,checkpoints", [("grid2048", [1, 10, 100]), ("random4096", [1, 10, 100]),
                                               ("dense4096", [1, 5, 20])])
 def test_committed_goldens(name, checkpoints):
