@@ -81,3 +81,18 @@ def test_oracle_reproduces_committed_goldens(name):
     out = make_golden.CASES[name]()
     for k in g.files:
         assert_bit_equal(out[k], g[k], f"{name}:{k}")
+
+
+def test_oracle_reproduces_the_full_size_checksum_at_step_1():
+    """The n = 4,194,304 sha256 fixture is an oracle output: re-derive its first entry
+    (one step; the later entries cost minutes and are left to make_golden.py --full)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(GOLD, "random4194304_sha256.json")))
+    sim = O.OracleSim(gold["n"], True)
+    sim.setup()
+    sim.step(1)
+    d = sim.download()
+    assert hashlib.sha256(np.ascontiguousarray(d["pos"]).tobytes()).hexdigest() == gold["steps"]["1"]["pos_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(d["rho"]).tobytes()).hexdigest() == gold["steps"]["1"]["rho_sha256"]
+    sim.close()
