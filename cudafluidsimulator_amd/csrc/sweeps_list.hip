@@ -90,8 +90,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #ifndef SL_ADDC
 #define SL_ADDC 1
 #endif
+#ifndef SL_K1_WAVES
+#define SL_K1_WAVES 0 // >0: ask for that many resident waves per SIMD (caps the VGPR budget)
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(SL_K1_THREADS) void k_density_mask_lds(DevParams P, SweepArgs A) {
+__global__
+#if SL_K1_WAVES
+__launch_bounds__(SL_K1_THREADS, SL_K1_WAVES)
+#else
+__launch_bounds__(SL_K1_THREADS)
+#endif
+void k_density_mask_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SL_K1_THREADS / SPH_WAVE][SW_CAP + SW_UNROLL];
     // Finished mask words wait here ([slot][lane]: conflict-free) until a lane has
     // SL_WBUF of them, then leave as 16-byte stores: single-word stores to 64
