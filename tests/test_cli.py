@@ -1,0 +1,67 @@
+"""The `./sph` command line (cudafluidsimulator_amd/csrc/main.cpp) keeps the reference's
+interface (main.cpp:12-55): -n / -i random|grid / -m free|time / -?, rejection of bad
+values with the usage text and exit status 1, and after `-m time` the five-line table
+of times.h (main.cpp:69-76)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPH = os.path.join(ROOT, "cudafluidsimulator_amd", "sph")
+
+USAGE = ("Program Options:\n"
+         "  -n  <NUM_PARTICLES>    Number of particles to simulate\n"
+         "  -i  <random/grid>      Initialization mode: random or grid\n"
+         "  -m  <free/time>        Execution mode: free or timed\n"
+         "  -?                     This message\n")
+
+
+def run(*args, env=None):
+    if not os.path.exists(SPH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cudafluidsimulator_amd", "csrc")],
+                              stdout=subprocess.DEVNULL)
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([SPH, *args], capture_output=True, text=True, timeout=120, env=e)
+
+
+@pytest.mark.parametrize("args,first", [(("-i", "bogus"), "Invalid argument for option -i: bogus\n"),
+                                        (("-m", "fast"), "Invalid argument for option -m: fast\n"),
+                                        (("-?",), "")])
+def test_bad_arguments_print_usage_and_exit_1(args, first):
+    r = run(*args)
+    assert r.returncode == 1
+    assert r.stdout == first + USAGE
+
+
+def test_without_a_gpu_the_cli_fails_loudly():
+    """No CPU fallback: where no device is visible the product refuses to run."""
+    r = run("-n", "100", "-i", "grid", "-m", "time", env={"HIP_VISIBLE_DEVICES": "-1",
+                                                          "ROCR_VISIBLE_DEVICES": "-1"})
+    assert r.returncode != 0
+    assert "Grid construction" not in r.stdout
+    assert r.stderr.strip() or r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_timed_run_prints_the_reference_table():
+    r = run("-n", "8192", "-i", "grid", "-m", "time")
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    i = next(k for k, l in enumerate(lines) if l.startswith("Operation"))
+    head, rule, grid, sph_, xfer = lines[i:i + 5]
+    assert head.split() == ["Operation", "Per", "frame", "Total"]
+    assert re.fullmatch(r"-+", rule)
+    for row, name in ((grid, "Grid construction"), (sph_, "SPH update"), (xfer, "Data transfer")):
+        assert row.startswith(name)
+        per_frame, total = re.findall(r"\d+\.\d{5}", row)      # "%.5f" like times.h:23-33
+        assert float(total) >= float(per_frame) >= 0.0
+    assert float(re.findall(r"\d+\.\d{5}", sph_)[1]) > 0.0
+
+
+@pytest.mark.gpu
+def test_free_mode_runs_headless():
+    r = run("-n", "4096", "-i", "random", "-m", "free", env={"SPH_FREE_FRAMES": "5"})
+    assert r.returncode == 0, r.stderr
