@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #define SL_WBUF 8 // mask words buffered per lane before they are stored (2 KiB per wave);
                   // measured: density 1.17 ms with 8, 1.26 ms with 16 (one resident wave fewer)
 #endif
+#ifndef SL_EXP_LDSONLY
+#define SL_EXP_LDSONLY 0
+#endif
 #ifndef SL_PV8
 #define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
@@ -497,7 +500,16 @@ void k_force_list(DevParams P, SweepArgs A) {
         // Two gathers are always in flight while a pair body is evaluated: the
         // loop is unrolled by two so the pipeline registers never move.  (Three in
         // flight: 99 VGPRs, four resident waves, 1.24 -> 1.44 ms.)
-#if SL_WINDOW
+#if SL_EXP_LDSONLY
+        // PERF-ONLY experiment (results wrong by construction): every hit is read from the
+        // wave's LDS slice at (j mod window) -- what the sweep would cost if all records
+        // came from LDS at this LDS footprint.
+#define SL_FETCH(j, p, v)
+#define SL_USE(j, p, v)                                                        \
+    p = win[2 * ((j) & (SL_WINDOW - 1))];                                      \
+    v = win[2 * ((j) & (SL_WINDOW - 1)) + 1];                                  \
+    body(p, v);
+#elif SL_WINDOW
         // fetch: issue the global gather only for lanes whose hit is outside the
         // window (fewer active lanes = fewer addresses for the TA); the LDS copy is
         // read when the hit is consumed.

@@ -56,10 +56,14 @@ def dense4096():
 CASES = {"grid2048": grid2048, "random4096": random4096, "dense4096": dense4096}
 
 
-def full_size_checksums(n=4194304, checkpoints=(1, 10, 30)):
+def full_size_checksums(n=4194304, checkpoints=(1, 10, 30, 50, 60, 80, 100), dump_dir=None):
     """BASELINE config 3 (-n 4194304 -i random) is too big to commit as arrays: the
     fixture is the sha256 of the oracle's position / density arrays (particle-id order,
-    raw fp32 bytes) at a few steps.  About two minutes of CPU."""
+    raw fp32 bytes) at steps through the whole 100-step run: pressure switches on at
+    step ~50 and cell occupancy reaches ~144 per cell by step 100,
+    so the late checkpoints cover pressureKernel's 1/r branch and the dense-cell paths
+    at full size.  About ten minutes of CPU on 8 cores.  dump_dir: also save the
+    oracle's key-sorted positions at each checkpoint (workload studies; not committed)."""
     import hashlib
     import json
     sim = O.OracleSim(n, True)
@@ -72,13 +76,20 @@ def full_size_checksums(n=4194304, checkpoints=(1, 10, 30)):
         d = sim.download()
         out["steps"][str(k)] = {"pos_sha256": hashlib.sha256(np.ascontiguousarray(d["pos"]).tobytes()).hexdigest(),
                                 "rho_sha256": hashlib.sha256(np.ascontiguousarray(d["rho"]).tobytes()).hexdigest()}
+        out["steps"][str(k)]["pair_tests"] = int(sim.last_pair_tests())
+        out["steps"][str(k)]["rho_max"] = float(d["rho"].max())
+        out["steps"][str(k)]["particles_with_pressure"] = int((d["rho"] > 1000.0).sum())
         print(n, k, out["steps"][str(k)], flush=True)
+        if dump_dir:
+            srt = sim.sorted_state()
+            np.savez(os.path.join(dump_dir, f"sorted_{n}_{k}.npz"), keys=srt["keys"], pos=srt["pos"])
     with open(os.path.join(HERE, f"random{n}_sha256.json"), "w") as f:
         json.dump(out, f, indent=1)
 
 if __name__ == "__main__":
     if "--full" in sys.argv:
-        full_size_checksums()
+        dd = sys.argv[sys.argv.index("--dump-dir") + 1] if "--dump-dir" in sys.argv else None
+        full_size_checksums(dump_dir=dd)
         sys.exit(0)
     for name, fn in CASES.items():
         out = fn()
