@@ -73,7 +73,7 @@ struct sph_handle {
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
     unsigned long long *maskCursor = nullptr;
-    unsigned long long maskCapacity = 0;
+    unsigned long long maskCapacity = 0; // quads (16 B)
     bool external = false;  // pos4/vel4 are caller-owned (sph_bind_buffers)
     hipStream_t ownCompute = nullptr;
     int *boundsDev = nullptr, *boundsHost = nullptr;
@@ -217,26 +217,34 @@ int alloc_device(sph_handle *h) {
     HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
     memset(h->hostPos, 0, posCap * 3 * sizeof(float));
     if (h->opt.sweep == SPH_SWEEP_LIST) {
-        // 128 dwords per particle slot = room for 64 (first candidate, mask) pairs,
-        // i.e. 2048 candidates; the worst-case reservation measured at n = 4,194,304
-        // random is 32 dwords early and 74 at step 100.  Denser fills need more: the
-        // reservation is 2 dwords per 32 candidates plus up to 2 per run, candidates =
+        // Hit-stream pool (sweeps_list.hip): a wave reserves Q quads (16 B = two (first
+        // candidate, mask) pairs) for each of its 64 lanes, Q = half the largest number
+        // of 32-candidate words any of its lanes can fill.  Candidates per particle =
         // 27 x particles per cell (about half the cells of the box hold particles with
-        // the reference initialisers), and it grows ~4x as the fluid settles.  A wave
-        // that finds the pool exhausted falls back to testing (sweeps_list.hip): at
-        // n = 16,777,216 that cost 7 % of the step with 128 dwords per slot.
+        // the reference initialisers) and grow ~4.7x as the fluid settles (measured at
+        // n = 4,194,304: 217 at step 1, 1011 at step 100, i.e. 9 -> 36 words per lane
+        // plus up to one partly filled word per run).  The pool is sized for 4x the
+        // initial fill + the per-run slack, never more than 40 % of the device memory
+        // that is free now; a wave that finds it exhausted falls back to testing every
+        // candidate again in the force sweep (k_force_fallback: same results, slower).
         const double ppc = (double)cap / (0.5 * (double)h->P.numCells);
-        const double est = 4.0 * (2.0 * 27.0 * ppc / 32.0 + 18.0);
-        unsigned long long perSlot = est > 128.0 ? (unsigned long long)est : 128ull;
-        unsigned long long words = (unsigned long long)cap * perSlot;
-        if (words < (1ull << 22)) words = 1ull << 22;
-        if (const char *e = getenv("SPH_MASK_POOL_WORDS")) words = strtoull(e, nullptr, 10);
-        if (words > 0xFFFFFFF0ull) words = 0xFFFFFFF0ull; // offsets are 32-bit
-        h->maskCapacity = words;
-        HIPCHK(h, hipMalloc(&h->maskPool, (size_t)(words ? words : 1) * sizeof(uint32_t)));
+        const double wordsPerLane = 4.0 * (27.0 * ppc / 32.0) + 12.0;
+        unsigned long long quads = (unsigned long long)((double)cap * wordsPerLane * 0.5 * 1.25);
+        if (quads < (1ull << 20)) quads = 1ull << 20;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const unsigned long long lim = (unsigned long long)(0.4 * (double)freeB) / sizeof(uint4);
+            if (quads > lim) quads = lim;
+        }
+        if (const char *e = getenv("SPH_MASK_POOL_WORDS")) quads = strtoull(e, nullptr, 10) / 4;
+        if (quads > 0xFFFFFFF0ull) quads = 0xFFFFFFF0ull; // wave bases are 32-bit quad indices
+        h->maskCapacity = quads;
+        HIPCHK(h, hipMalloc(&h->maskPool, (size_t)(quads ? quads : 1) * sizeof(uint4)));
         HIPCHK(h, hipMalloc(&h->pv8, cap * 2 * sizeof(float4)));
-        HIPCHK(h, hipMalloc(&h->maskOff, cap * 2 * sizeof(uint32_t))); // {first dword, dwords}
-        HIPCHK(h, hipMemset(h->maskOff, 0xFF, cap * 2 * sizeof(uint32_t)));
+        // per 64-particle wave: {base of its quads or ~0u, quads per lane}
+        const size_t hdrWords = 2 * ((cap + 63) / 64 + 1);
+        HIPCHK(h, hipMalloc(&h->maskOff, hdrWords * sizeof(uint32_t)));
+        HIPCHK(h, hipMemset(h->maskOff, 0xFF, hdrWords * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->maskCursor, sizeof(unsigned long long)));
         HIPCHK(h, hipMemset(h->maskCursor, 0, sizeof(unsigned long long)));
     }
@@ -572,7 +580,7 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
 
 const char *sph_build_info(void) {
     return "libsph_hip gfx950 (MI355X/CDNA4), api v1, strict-fp32 sweeps, "
-           "8-bit LSD radix grid build";
+           "8/10-bit LSD radix grid build";
 }
 
 int sph_default_settings(SphSettings *out, int numParticles, int randomInit) {

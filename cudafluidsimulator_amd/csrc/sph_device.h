@@ -99,10 +99,10 @@ struct SweepArgs {
     int n_all;
     int tileChunk;            // xcd_tile(): 256-particle tiles per chunk (1/8 z-layer), 0 = eighths
     // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
-    uint32_t *maskPool;               // pool of 32-candidate mask words
-    uint32_t *maskOff;                // per sorted particle: {first dword or ~0u, dwords}
-    unsigned long long *maskCursor;   // words handed out this step
-    unsigned long long maskCapacity;  // pool size in words
+    uint32_t *maskPool;               // pool of quads: two (first candidate, 32-bit mask) pairs each
+    uint32_t *maskOff;                // per 64-particle wave: {first quad or ~0u, quads per lane}
+    unsigned long long *maskCursor;   // quads handed out this step
+    unsigned long long maskCapacity;  // pool size in quads
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
     const int *listHead;              // [numCells] first particle of the cell or -1

@@ -53,16 +53,6 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_K2_THREADS
 #define SL_K2_THREADS 64
 #endif
-#ifndef SL_PAIRQ
-#define SL_PAIRQ 2 // 0, 2 or 4: the force sweep refills that many pairs at a time (aligned lane streams)
-#endif
-#ifndef SL_VCONST
-#define SL_VCONST 0
-#endif
-#ifndef SL_WBUF
-#define SL_WBUF 8 // mask words buffered per lane before they are stored (2 KiB per wave);
-                  // measured: density 1.17 ms with 8, 1.26 ms with 16 (one resident wave fewer)
-#endif
 #ifndef SL_EXP_LDSONLY
 #define SL_EXP_LDSONLY 0
 #endif
@@ -71,78 +61,87 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
 #endif
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < SPH_WAVE; off <<= 1) {
-        uint32_t t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-
 // ---------------------------------------------------------------------------
 // density + hit masks, LDS-staged (production).  Same wave-autonomous walk as
 // k_density_lds: the wave stages the union of its lanes' ranges of one run in
 // LDS and every lane walks its own range from its first candidate, four per
 // trip.  All lanes of the wave are at the same candidate ORDINAL k at any time,
 // so the mask bit position (k & 31) is wave-uniform: recording a hit costs a
-// compare and an add-with-carry (m = 2m + hit), and whole words are bit-reversed
-// and flushed every eighth trip.  A run whose union does not fit the slice (dense cells) is walked
-// in the same lock-step straight from global memory.
+// compare and an add-with-carry (m = 2m + hit), and a whole word is bit-reversed
+// and handed over every eighth trip.  A run whose union does not fit the slice
+// (dense cells) is walked in the same lock-step straight from global memory.
+//
+// Hit stream layout ("wave-transposed"): the wave owns Q quads per lane,
+// quad q of lane l at maskPool[(base + q*64 + l) * 4 .. +4) = {j0, m0, j1, m1}:
+// two (first candidate, 32-bit hit mask) pairs.  A lane writes only its
+// NON-EMPTY words, compacted, and ends its sequence with a zero mask (unless
+// it fills all 2Q pairs), so the force sweep reads pairs until it meets m == 0.
+// Lanes complete quads at about the same time, so a quad store is (mostly) one
+// contiguous kilobyte per wave and every cache line is filled by neighbouring
+// lanes within a few hundred cycles -- round 1's per-lane contiguous streams
+// cost 0.93 GB of partial-line WRITE_SIZE per launch for 0.45 GB of pairs
+// and an LDS staging buffer per wave (profiles/r01_pmc_hbm_v10.csv).
+// Per wave header: maskOff[2w] = base in quads (or SL_NONE: pool exhausted ->
+// k_force_fallback), maskOff[2w+1] = Q.
 // ---------------------------------------------------------------------------
 #ifndef SL_ADDC
 #define SL_ADDC 1
 #endif
 #ifndef SL_K1_WAVES
-#define SL_K1_WAVES 0 // >0: ask for that many resident waves per SIMD (caps the VGPR budget)
+#define SL_K1_WAVES 6 // resident waves per SIMD asked for (caps the VGPR budget at 80); measured: 5..8 the same
 #endif
-template <bool FAST>
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// SAMECUT: the force cut-off P.cut2 (largest dist2 with sqrtf(dist2) <= h) equals h*h --
+// true for the reference's h = 0.1f.  The hit bit is then the sign of h2 - dist2, which the
+// density term needs anyway, and one v_alignbit_b32 shifts it in (miss = 1; the word is
+// complemented when it is handed over) instead of a compare and an add-with-carry.
+template <bool FAST, bool SAMECUT>
 __global__
 #if SL_K1_WAVES
-__launch_bounds__(SL_K1_THREADS, SL_K1_WAVES)
+__launch_bounds__(SL_K1_THREADS, SL_K1_WAVES * SL_K1_THREADS / 64)
 #else
 __launch_bounds__(SL_K1_THREADS)
 #endif
 void k_density_mask_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SL_K1_THREADS / SPH_WAVE][SW_CAP + SW_UNROLL];
-    // Finished mask words wait here ([slot][lane]: conflict-free) until a lane has
-    // SL_WBUF of them, then leave as 16-byte stores: single-word stores to 64
-    // different streams made every word a partial-line write (measured 2.0 GB of
-    // WRITE_SIZE per launch for 0.28 GB of masks).
-    __shared__ uint32_t wbufAll[SL_K1_THREADS / SPH_WAVE][SL_WBUF * SPH_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
-    uint32_t *wbuf = wbufAll[w] + lane;
     SL_STAMP(t0);
 #if SW_STAMPS
     unsigned long long accStage = 0, accTest = 0;
 #endif
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K1_THREADS)) * blockDim.x + threadIdx.x;
+    const int wv = xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K1_THREADS)) * (SL_K1_THREADS / SPH_WAVE) + w;
+    const int i = A.i_begin + wv * SPH_WAVE + lane;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
     int js[9], je[9];
     load_runs(P, A.cellRange, c, valid, js, je);
 
-    // pool space for the worst case: one (first candidate, mask) pair per 32 candidates
-    uint32_t words = 0, pairs = 0;
+    // pool space: a lane stores at most one pair per 32 candidates of each run
+    int words = 0;
+    uint32_t pairs = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-        words += 2u * ((uint32_t)(je[r] - js[r] + 31) >> 5);
+        words += (je[r] - js[r] + 31) >> 5;
         pairs += (uint32_t)(je[r] - js[r]);
     }
-#if SL_PAIRQ
-    words = (words + 2u * SL_PAIRQ - 1u) & ~(2u * SL_PAIRQ - 1u); // lane streams start on a load boundary
-#endif
-    const uint32_t incl = wave_incl_scan_u32(words, lane);
-    const uint32_t total = __shfl(incl, 63);
+    const int Q = __builtin_amdgcn_readfirstlane((wave_max_i32(words) + 1) >> 1); // quads per lane
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(A.maskCursor, (unsigned long long)total);
-    base = (unsigned long long)__shfl((unsigned)(base >> 32), 0) << 32 |
-           (unsigned long long)__shfl((unsigned)base, 0);
-    const bool ok = base + total <= A.maskCapacity; // wave-uniform
-    uint32_t woff = ok ? (uint32_t)base + (incl - words) : SL_NONE;
-    const uint32_t woff0 = woff;
+    if (lane == 0) base = atomicAdd(A.maskCursor, (unsigned long long)Q * SPH_WAVE);
+    base = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32 |
+           (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
+    const bool ok = base + (unsigned long long)Q * SPH_WAVE <= A.maskCapacity; // in quads; wave-uniform
+    if (lane == 0 && i < A.i_end) {
+        A.maskOff[2 * (size_t)wv] = ok ? (uint32_t)base : SL_NONE;
+        A.maskOff[2 * (size_t)wv + 1] = (uint32_t)Q;
+    }
+    uint4 *const myq = reinterpret_cast<uint4 *>(A.maskPool) + (ok ? base : 0ull) + lane;
     if (A.pairCounter) {
         uint32_t s = wave_sum_u32(pairs);
         if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
@@ -152,41 +151,31 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
     const float4 *const sent = stage + SW_CAP;
     float rho = 0.f;
 #if SW_STAMPS
-    asm volatile("" ::"v"(js[0] + je[8] + (int)woff));
+    asm volatile("" ::"v"(js[0] + je[8]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
     SL_STAMP(t1);
-#if SL_VCONST
-    float h2v = P.h2, dcv = P.dcoef, cut2v = P.cut2;
-    asm volatile("" : "+v"(h2v), "+v"(dcv), "+v"(cut2v));
-#endif
-#if SL_ADDC
-    float cut2r = P.cut2; // in a VGPR once: the compare below cannot take an SGPR there
-    asm volatile("" : "+v"(cut2r));
-#endif
-    int pend = 0; // words of this lane waiting in wbuf
-    // write this lane's pending words (4 at a time) and empty its buffer
-    auto flush_words = [&]() {
-#pragma unroll
-        for (int q = 0; q < SL_WBUF; q += 4) {
-            if (q < pend) {
-                uint4 v;
-                v.x = wbuf[(q + 0) * SPH_WAVE];
-                v.y = wbuf[(q + 1) * SPH_WAVE];
-                v.z = wbuf[(q + 2) * SPH_WAVE];
-                v.w = wbuf[(q + 3) * SPH_WAVE];
-                uint32_t *dst = A.maskPool + woff + q;
-                if (q + 4 <= pend) {
-                    *reinterpret_cast<uint4 *>(dst) = v; // global_store_dwordx4 (dword aligned)
-                } else {
-                    dst[0] = v.x;
-                    if (q + 1 < pend) dst[1] = v.y;
-                    if (q + 2 < pend) dst[2] = v.z;
-                }
+    // VALU ops with an SGPR or literal source issue at half rate on gfx950
+    // (scripts/microbench/valu_rate.hip): the loop constants live in VGPRs
+    float h2v = P.h2, dcv = P.dcoef, cut2r = P.cut2, massv = SPH_MASS;
+    asm volatile("" : "+v"(h2v), "+v"(dcv), "+v"(cut2r), "+v"(massv));
+    // this lane's pending pair and the number of quads it has stored
+    uint32_t pj0 = 0, pm0 = 0;
+    bool pending = false;
+    int qidx = 0;
+    // hand a finished word over: non-empty words only, two per 16-byte store
+    auto emit = [&](uint32_t jbase, uint32_t mask) {
+        if (ok && mask != 0) {
+            if (!pending) {
+                pj0 = jbase;
+                pm0 = mask;
+                pending = true;
+            } else {
+                myq[(size_t)qidx * SPH_WAVE] = make_uint4(pj0, pm0, jbase, mask);
+                ++qidx;
+                pending = false;
             }
         }
-        woff += (uint32_t)pend;
-        pend = 0;
     };
     const int rowId = c.y + c.z * P.D;
     unsigned long long todo = __ballot(valid);
@@ -211,6 +200,36 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
             }
         }
     }
+    // One run of one pass: this lane's range, the wave's union, staged or not.
+    struct Run {
+        int jsr, len, u0, ulen;
+        bool any, staged;
+    };
+    auto describe = [&](int r, bool act) -> Run {
+        int jsr = js[0], jer = je[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) { // r is wave-uniform: scalar-conditioned moves
+            jsr = (r == q) ? js[q] : jsr;
+            jer = (r == q) ? je[q] : jer;
+        }
+        Run R;
+        const bool nonempty = act && jer > jsr;
+        const unsigned long long mm = __ballot(nonempty);
+        R.any = mm != 0;
+        const int lo = mm ? __ffsll((long long)mm) - 1 : 0;
+        const int hi = mm ? 63 - __clzll((long long)mm) : 0;
+        R.u0 = __builtin_amdgcn_readlane(jsr, lo);
+        R.ulen = R.any ? __builtin_amdgcn_readlane(jer, hi) - R.u0 : 0;
+        R.staged = R.ulen <= SW_CAP; // wave-uniform
+        R.jsr = nonempty ? jsr : R.u0;
+        R.len = nonempty ? jer - jsr : 0; // this lane's candidates
+        return R;
+    };
+    // (measured, round 2: fetching the union of run r+1 into registers while run r is
+    // tested changes nothing -- 1.138 vs 1.139 ms -- and neither does the resident wave
+    // count between 5 and 8 per SIMD: the sweep is bound by VALU issue at the ~3.1
+    // cycles per non-FMA wave-instruction that scripts/microbench/valu_rate.hip measures,
+    // not by the latency of the nine staging round trips.)
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int rowL = __builtin_amdgcn_readlane(rowId, leader);
@@ -218,25 +237,10 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
         todo &= ~__ballot(act);
 #pragma unroll 1
         for (int r = 0; r < 9; ++r) {
-            int jsr = js[0], jer = je[0];
-#pragma unroll
-            for (int q = 1; q < 9; ++q) { // r is wave-uniform: scalar-conditioned moves
-                jsr = (r == q) ? js[q] : jsr;
-                jer = (r == q) ? je[q] : jer;
-            }
-            const bool nonempty = act && jer > jsr;
-            const unsigned long long mm = __ballot(nonempty);
-            if (!mm) continue;
-            const int lo = __ffsll((long long)mm) - 1;
-            const int hi = 63 - __clzll((long long)mm);
-            const int u0 = __builtin_amdgcn_readlane(jsr, lo);
-            const int u1 = __builtin_amdgcn_readlane(jer, hi);
-            const int len = nonempty ? jer - jsr : 0;          // this lane's candidates
-
-            const bool staged = (u1 - u0) <= SW_CAP;           // wave-uniform
+            const Run R = describe(r, act);
             SL_STAMP(tA);
-            if (staged) {
-                for (int k = lane; k < u1 - u0; k += SPH_WAVE) stage[k] = A.pos4[u0 + k];
+            if (R.any && R.staged) { // the union of the wave's ranges of this run -> LDS slice
+                for (int k = lane; k < R.ulen; k += SPH_WAVE) stage[k] = A.pos4[R.u0 + k];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #if SW_STAMPS
@@ -244,102 +248,101 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
 #endif
             }
             SL_STAMP(tB);
-            const float4 *cur = stage + (nonempty ? jsr - u0 : 0);
-            const float4 *gcur = A.pos4 + (nonempty ? jsr : 0);
-            uint32_t m = 0;
-            int k = 0;
-            // four candidates of one trip: density terms, hit bits, word hand-over
-            auto trip = [&](const float4 (&pj)[SW_UNROLL]) {
-#if SL_VCONST
-                // VALU ops with an SGPR source issue at half rate on gfx950
-                // (scripts/microbench/valu_rate.hip): keep the constants in VGPRs
-                const float h2 = h2v, dcoef = dcv, cut2 = cut2v;
-#else
-                const float h2 = P.h2, dcoef = P.dcoef, cut2 = P.cut2;
-#endif
-#pragma unroll
-                for (int u = 0; u < SW_UNROLL; ++u) {
-                    float dx = pi.x - pj[u].x;
-                    float dy = pi.y - pj[u].y;
-                    float dz = pi.z - pj[u].z;
-                    float dist2;
-                    if (FAST) {
-                        dist2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        const float diff = fmaxf(h2 - dist2, 0.f);
-                        rho = __builtin_fmaf((SPH_MASS * dcoef) * (diff * diff), diff, rho);
-                    } else {
-                        dist2 = dx * dx + dy * dy + dz * dz;
-                        const float diff = fmaxf(h2 - dist2, 0.f);
-                        rho += SPH_MASS * (dcoef * diff * diff * diff);
-                    }
-#if SL_ADDC
-                    // hit bit shifted in through the carry: m = 2m + !(dist2 > cut2), two
-                    // VALU ops per candidate instead of mov + cmp + cndmask + or.  The word
-                    // fills from the top, so it is bit-reversed once when it is handed over.
-                    asm("v_cmp_ngt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-                        : "+v"(m)
-                        : "v"(dist2), "v"(cut2r)
-                        : "vcc");
-#else
-                    const uint32_t bit = 1u << ((k + u) & 31); // wave-uniform
-                    m |= !(dist2 > cut2) ? bit : 0u;
-#endif
-                }
-#pragma unroll
-                for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
-                if (((k + SW_UNROLL) & 31) == 0) { // a whole word is complete (wave-uniform)
-                    if (ok && m != 0) { // empty words are not stored
-                        wbuf[pend++ * SPH_WAVE] = (uint32_t)(jsr + (k & ~31));
-#if SL_ADDC
-                        wbuf[pend++ * SPH_WAVE] = __builtin_bitreverse32(m);
-#else
-                        wbuf[pend++ * SPH_WAVE] = m;
-#endif
-                    }
-                    m = 0;
-                    if (__ballot(pend >= SL_WBUF)) flush_words();
-                }
-            };
-            // (measured: a select-free first phase -- trips in which every lane still has
-            // four candidates, found with a DPP wave-min -- saves 8 of ~78 VALU ops in
-            // about half the trips and 0.5 % of the kernel: not kept)
-            // (two copies of the loop rather than one with a select in it: joining
-            // the LDS and the global candidates cost 20 register moves per trip)
-            if (staged) {
-                for (; __ballot(k < len); k += SW_UNROLL) {
-                    float4 pj[SW_UNROLL];
+            if (R.any) {
+                const int jsr = R.jsr, len = R.len;
+                const float4 *cur = stage + (jsr - R.u0);
+                const float4 *gcur = A.pos4 + jsr;
+                uint32_t m = 0;
+                int k = 0;
+                // four candidates of one trip: density terms, hit bits, word hand-over
+                auto trip = [&](const float4 (&pj)[SW_UNROLL]) {
 #pragma unroll
                     for (int u = 0; u < SW_UNROLL; ++u) {
-                        const float4 *p = (k + u < len) ? cur + k : sent;
-                        pj[u] = p[u];
-                    }
-                    trip(pj);
-                }
-            } else {
-                for (; __ballot(k < len); k += SW_UNROLL) {
-                    float4 pj[SW_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < SW_UNROLL; ++u) {
-                        const bool in = k + u < len;
-                        pj[u] = gcur[in ? k + u : 0];
-                        pj[u].x = in ? pj[u].x : 1e18f; // out of range: fails every radius test
-                    }
-                    trip(pj);
-                }
-            }
-            if ((k & 31) != 0) { // last, partial word
-                if (ok && m != 0) {
-                    wbuf[pend++ * SPH_WAVE] = (uint32_t)(jsr + (k & ~31));
+                        float dx = pi.x - pj[u].x;
+                        float dy = pi.y - pj[u].y;
+                        float dz = pi.z - pj[u].z;
+                        float dist2;
+                        float draw;
+                        if (FAST) {
+                            dist2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                            draw = h2v - dist2;
+                            const float diff = fmaxf(draw, 0.f);
+                            rho = __builtin_fmaf((massv * dcv) * (diff * diff), diff, rho);
+                        } else {
+                            dist2 = dx * dx + dy * dy + dz * dz;
+                            draw = h2v - dist2;
+                            const float diff = fmaxf(draw, 0.f);
+                            rho += massv * (dcv * diff * diff * diff);
+                        }
+                        if (SAMECUT) { // m = 2m + (dist2 > h2): one op
+                            m = __builtin_amdgcn_alignbit(m, __float_as_uint(draw), 31);
+                            continue;
+                        }
 #if SL_ADDC
-                    wbuf[pend++ * SPH_WAVE] = __builtin_bitreverse32(m) >> (32 - (k & 31));
+                        // hit bit shifted in through the carry: m = 2m + !(dist2 > cut2), two
+                        // VALU ops per candidate instead of mov + cmp + cndmask + or.  The word
+                        // fills from the top, so it is bit-reversed once when it is handed over.
+                        asm("v_cmp_ngt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                            : "+v"(m)
+                            : "v"(dist2), "v"(cut2r)
+                            : "vcc");
 #else
-                    wbuf[pend++ * SPH_WAVE] = m;
+                        const uint32_t bit = 1u << ((k + u) & 31); // wave-uniform
+                        m |= !(dist2 > cut2r) ? bit : 0u;
+#endif
+                    }
+#pragma unroll
+                    for (int u = 0; u < SW_UNROLL; ++u) asm volatile("" ::"v"(pj[u].w));
+                    if (((k + SW_UNROLL) & 31) == 0) { // a whole word is complete (wave-uniform)
+                        if (SAMECUT) emit((uint32_t)(jsr + (k & ~31)), ~__builtin_bitreverse32(m));
+                        else
+#if SL_ADDC
+                            emit((uint32_t)(jsr + (k & ~31)), __builtin_bitreverse32(m));
+#else
+                            emit((uint32_t)(jsr + (k & ~31)), m);
+#endif
+                        m = 0;
+                    }
+                };
+                // (measured: a select-free first phase -- trips in which every lane still has
+                // four candidates, found with a DPP wave-min -- saves 8 of ~78 VALU ops in
+                // about half the trips and 0.5 % of the kernel: not kept)
+                // (two copies of the loop rather than one with a select in it: joining
+                // the LDS and the global candidates cost 20 register moves per trip)
+                if (R.staged) {
+                    for (; __ballot(k < len); k += SW_UNROLL) {
+                        float4 pj[SW_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < SW_UNROLL; ++u) {
+                            const float4 *p = (k + u < len) ? cur + k : sent;
+                            pj[u] = p[u];
+                        }
+                        trip(pj);
+                    }
+                } else {
+                    for (; __ballot(k < len); k += SW_UNROLL) {
+                        float4 pj[SW_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < SW_UNROLL; ++u) {
+                            const bool in = k + u < len;
+                            pj[u] = gcur[in ? k + u : 0];
+                            pj[u].x = in ? pj[u].x : 1e18f; // out of range: fails every radius test
+                        }
+                        trip(pj);
+                    }
+                }
+                if ((k & 31) != 0) { // last, partial word
+                    if (SAMECUT) emit((uint32_t)(jsr + (k & ~31)), (~__builtin_bitreverse32(m)) >> (32 - (k & 31)));
+                    else
+#if SL_ADDC
+                        emit((uint32_t)(jsr + (k & ~31)), __builtin_bitreverse32(m) >> (32 - (k & 31)));
+#else
+                        emit((uint32_t)(jsr + (k & ~31)), m);
 #endif
                 }
-                if (__ballot(pend >= SL_WBUF)) flush_words();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
 #if SW_STAMPS
             {
                 SL_STAMP(tC);
@@ -350,10 +353,9 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
         }
     }
     SL_STAMP(t2);
-    if (ok) flush_words();
-    if (valid) { // where this particle's pairs start and how many dwords they take
-        A.maskOff[2 * (size_t)i] = woff0;
-        A.maskOff[2 * (size_t)i + 1] = ok ? woff - woff0 : 0u;
+    if (ok && valid) { // end of this lane's sequence: a zero mask, unless all 2Q pairs are used
+        if (pending) myq[(size_t)qidx * SPH_WAVE] = make_uint4(pj0, pm0, 0u, 0u);
+        else if (qidx < Q) myq[(size_t)qidx * SPH_WAVE] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (valid) {
         rho = fmaxf(rho, SPH_EPS_F);
@@ -370,7 +372,7 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
             atomicAdd(S + 3, accTest);   // test loops incl. mask hand-over
             atomicAdd(S + 4, t3 - t0);   // whole wave
             atomicAdd(S + 5, 1ull);      // waves
-            atomicAdd(S + 13, t3 - t2);  // final flush + stores
+            atomicAdd(S + 13, t3 - t2);  // final stores
         }
     }
 #endif
@@ -401,9 +403,11 @@ void k_force_list(DevParams P, SweepArgs A) {
     float4 pi = A.pos4[iSafe];
     const float4 vi = A.vel4[iSafe];
     const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
-    // this particle's stream of (first candidate, 32-bit hit mask) pairs
-    const uint32_t off = valid ? A.maskOff[2 * (size_t)i] : 0u;
-    const int total = valid ? (int)A.maskOff[2 * (size_t)i + 1] : 0; // dwords
+    // this wave's hit stream (layout: k_density_mask_lds): Q quads per lane, quad q of
+    // this lane at stream4[q * 64] = two (first candidate, 32-bit hit mask) pairs
+    const int wv = tileIdx * (SL_K2_THREADS / SPH_WAVE) + (threadIdx.x >> 6);
+    const uint32_t baseq = __builtin_amdgcn_readfirstlane(A.maskOff[2 * (size_t)wv]);
+    const int Q = __builtin_amdgcn_readfirstlane((int)A.maskOff[2 * (size_t)wv + 1]);
     ForceAcc F = {0.f, 0.f, 0.f};
 
 #if SL_WINDOW
@@ -428,35 +432,27 @@ void k_force_list(DevParams P, SweepArgs A) {
     // A wave that found the mask pool exhausted has no stream: its particles are
     // handled by k_force_fallback (kept out of this kernel: its 27 table reads and
     // run arrays would cost two resident waves per SIMD here).
-    if (__ballot(valid && off == SL_NONE)) return;
+    if (baseq == SL_NONE) return;
     {
-        const uint2 *stream = reinterpret_cast<const uint2 *>(A.maskPool + off);
-        const int npairs = total >> 1;
         // Bit cursor.  (jb, m): first candidate and remaining bits of the current
-        // pair; (jbn, mn): the next pair, already in flight.  pop() returns the next
-        // hit's sorted index, or the particle itself once the stream is exhausted
-        // (dist = 0 gates every term: exact no-op).
-#if SL_PAIRQ
-        // SL_PAIRQ pairs per refill (16-byte loads): fewer stream loads and cache-line touches
-        const uint4 *stream4 = reinterpret_cast<const uint4 *>(A.maskPool + off);
-        const int nq = (npairs + SL_PAIRQ - 1) / SL_PAIRQ;
+        // pair; (jq, mq): the pairs of the last quad loaded.  A lane's sequence ends
+        // with a zero mask (or after Q quads).  pop() returns the next hit's sorted
+        // index, or the particle itself once the stream is exhausted (dist = 0 gates
+        // every term: exact no-op).
+        const uint4 *stream4 = reinterpret_cast<const uint4 *>(A.maskPool) + baseq + (threadIdx.x & 63);
+        const int nq = valid ? Q : 0;
         int wq = 0;
-        uint32_t m = 0, mq[SL_PAIRQ];
-        int jb = 0, jq[SL_PAIRQ];
-#pragma unroll
-        for (int u = 0; u < SL_PAIRQ; ++u) { mq[u] = 0; jq[u] = 0; }
+        uint32_t m = 0, mq[2] = {0u, 0u};
+        int jb = 0, jq[2] = {0, 0};
         bool live = true;
         auto fetch = [&]() {
             if (wq < nq) {
-#pragma unroll
-                for (int u = 0; u < SL_PAIRQ; u += 2) {
-                    const uint4 t = stream4[wq * (SL_PAIRQ / 2) + u / 2];
-                    jq[u] = (int)t.x;
-                    mq[u] = (SL_PAIRQ * wq + u < npairs) ? t.y : 0u; // beyond the count: padding
-                    jq[u + 1] = (int)t.z;
-                    mq[u + 1] = (SL_PAIRQ * wq + u + 1 < npairs) ? t.w : 0u;
-                }
-                ++wq;
+                const uint4 t = stream4[(size_t)wq * SPH_WAVE];
+                jq[0] = (int)t.x;
+                mq[0] = t.y;
+                jq[1] = (int)t.z;
+                mq[1] = t.w;
+                wq = (t.w == 0u) ? nq : wq + 1; // a zero mask ends the sequence
             }
         };
         fetch();
@@ -464,30 +460,12 @@ void k_force_list(DevParams P, SweepArgs A) {
             if (m == 0) { // next pair; stored masks are never 0, so mq[0] == 0 means "queue empty"
                 m = mq[0];
                 jb = jq[0];
-#pragma unroll
-                for (int u = 0; u + 1 < SL_PAIRQ; ++u) { mq[u] = mq[u + 1]; jq[u] = jq[u + 1]; }
-                mq[SL_PAIRQ - 1] = 0;
+                mq[0] = mq[1];
+                jq[0] = jq[1];
+                mq[1] = 0;
                 if (mq[0] == 0) fetch();
             }
-#else
-        int wi = 0;
-        uint32_t m = 0, mn = 0;
-        int jb = 0, jbn = 0;
-        bool live = true;
-        if (wi < npairs) { const uint2 t = stream[wi]; jbn = (int)t.x; mn = t.y; ++wi; }
-        auto pop = [&]() -> int {
-            if (m == 0) { // take the prefetched pair, start fetching the one after
-                m = mn;
-                jb = jbn;
-                mn = 0;
-                if (wi < npairs) { const uint2 t = stream[wi]; jbn = (int)t.x; mn = t.y; ++wi; }
-            }
-#endif
-#if SL_PAIRQ
             live = (m | mq[0]) != 0;
-#else
-            live = (m | mn) != 0;
-#endif
             const bool has = m != 0;
             const int b = has ? __builtin_ctz(m) : 0;
             m &= m - 1u; // (0 stays 0)
@@ -559,8 +537,14 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SL_K1_THREADS - 1) / SL_K1_THREADS;
-    if (mathMode == 1) k_density_mask_lds<true><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
-    else k_density_mask_lds<false><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
+    const bool same = P.cut2 == P.h2;
+    if (mathMode == 1) {
+        if (same) k_density_mask_lds<true, true><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
+        else k_density_mask_lds<true, false><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
+    } else {
+        if (same) k_density_mask_lds<false, true><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
+        else k_density_mask_lds<false, false><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
+    }
 }
 
 // Particles whose wave found the mask pool exhausted in the density sweep: test
@@ -569,7 +553,7 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
 template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, SweepArgs A) {
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = i < A.i_end && A.maskOff[2 * (size_t)i] == SL_NONE;
+    const bool mine = i < A.i_end && A.maskOff[2 * (size_t)((i - A.i_begin) >> 6)] == SL_NONE;
     if (!__ballot(mine)) return;
     const int iSafe = mine ? i : A.i_begin;
     float4 pi = A.pos4[iSafe];

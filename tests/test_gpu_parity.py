@@ -238,22 +238,27 @@ def test_fast_math_mode_within_north_star_tolerance():
     sim.close()
 
 
+@pytest.mark.parametrize("hh,box", [(0.2, 6.4), (0.25, 8.0)])
 @pytest.mark.parametrize("sweep", SWEEPS)
-def test_non_default_settings(sweep):
-    """Nothing is hard-wired to the reference's 100^3 grid: a 6.4-unit box with
-    h = 0.2 (32 cells per axis), a larger time step, 3001 particles."""
+def test_non_default_settings(sweep, hh, box):
+    """Nothing is hard-wired to the reference's 100^3 grid: a 32-cell box with
+    h = 0.2 or 0.25, a larger time step, 3001 particles.  h = 0.25f is a radius
+    for which the largest dist2 with sqrtf(dist2) <= h lies one ulp ABOVE h*h
+    (viscosityKernel tests r, pressureKernel r^2: simulator.cu:105,125), so the
+    list sweep's general hit-bit path runs; for 0.1f and 0.2f the two cut-offs
+    coincide and the sign-bit path runs."""
     import ctypes as C
     n = 3001
     rng = np.random.default_rng(3)
     s = sph.default_settings(n, False)
-    s.h = 0.2
-    s.boxDim = 6.4
+    s.h = hh
+    s.boxDim = box
     s.numCellsPerDim = 32
     s.timestep = 0.004
     h = np.float32(s.h)
     s.v_kernel_coeff = float(np.float32(45.0) / (np.float32(3.14159265) * np.float32(float(h) ** 6)))
     s.d_kernel_coeff = float(np.float32(315.0) / (np.float32(64.0) * np.float32(3.14159265) * np.float32(float(h) ** 9)))
-    pos = rng.uniform(0.3, 6.1, (n, 3)).astype(np.float32)
+    pos = rng.uniform(1.5 * hh, box - 1.5 * hh, (n, 3)).astype(np.float32)
     vel = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
     sim = sph.Simulator(s, sweep=sweep)
     sim.upload_state(pos, vel)
