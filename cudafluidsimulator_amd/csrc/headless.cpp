@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "sha256.h"
 #include "simulator.h"
 
 bool mouseClicked = false;
@@ -26,4 +27,7 @@ void startVisualization(Simulator *simulator) {
     const float3 *p = simulator->getPosition();
     if (p && simulator->settings->numParticles > 0)
         printf("particle 0 after %d frames: (%f, %f, %f)\n", frames, p[0].x, p[0].y, p[0].z);
+    if (p && getenv("SPH_PRINT_SHA256"))
+        printf("positions_sha256 %s\n",
+               sha256_hex(p, (size_t)simulator->settings->numParticles * sizeof(float3)).c_str());
 }

@@ -2,15 +2,19 @@
 //   -n <NUM_PARTICLES>  -i <random/grid>  -m <free/time>  -?
 // Same defaults (1000 / grid / time), same rejection of bad -i/-m values, same
 // derived constants, 100 timed steps and the same table.  One extra,
-// machine-readable line follows the table.
+// machine-readable line follows the table; with SPH_PRINT_SHA256 set, one more line
+// holds the sha256 of the getPosition() array (numParticles x float3, particle-id
+// order) so tests can compare this C++ path with the oracle's checksums.
 #include <unistd.h>
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <string>
 
+#include "sha256.h"
 #include "simulator.h"
 
 void startVisualization(Simulator *simulator);
@@ -71,11 +75,13 @@ int main(int argc, char **argv) {
         Times times;
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < numIters; i++) simulator->simulateAndTime(&times);
-        simulator->getPosition(); // last frame's positions have landed
+        const float3 *last = simulator->getPosition(); // last frame's positions have landed
         double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         displayTimes(&times);
         printf("{\"particle_steps_per_s\": %.6e, \"n\": %d, \"steps\": %d, \"wall_s\": %.6f}\n",
                (double)numParticles * numIters / wall, numParticles, numIters, wall);
+        if (getenv("SPH_PRINT_SHA256") && last)
+            printf("positions_sha256 %s\n", sha256_hex(last, (size_t)numParticles * sizeof(float3)).c_str());
     } else {
         glutInit(&argc, argv);
         startVisualization(simulator);

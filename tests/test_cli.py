@@ -65,3 +65,76 @@ def test_timed_run_prints_the_reference_table():
 def test_free_mode_runs_headless():
     r = run("-n", "4096", "-i", "random", "-m", "free", env={"SPH_FREE_FRAMES": "5"})
     assert r.returncode == 0, r.stderr
+
+
+def _sha_of(stdout):
+    m = re.search(r"^positions_sha256 ([0-9a-f]{64})$", stdout, re.M)
+    assert m, stdout
+    return m.group(1)
+
+
+@pytest.mark.gpu
+def test_cli_result_equals_the_c_abi_path_and_the_oracle():
+    """The C++ `Simulator` behind ./sph (the drop-in surface itself) is checked
+    numerically, not just for its table: sha256 of getPosition() after the 100 steps
+    of `-m time` equals the ctypes path's and the CPU oracle's on the same input."""
+    import hashlib
+
+    import numpy as np
+
+    import cudafluidsimulator_amd as sph
+    from oracle import oracle as O
+
+    n = 8192
+    r = run("-n", str(n), "-i", "grid", "-m", "time", env={"SPH_PRINT_SHA256": "1"})
+    assert r.returncode == 0, r.stderr
+    got = _sha_of(r.stdout)
+    sim = sph.Simulator(sph.default_settings(n, False))
+    sim.setup()
+    t = sph.Times()
+    for _ in range(100):
+        sim.simulateAndTime(t)
+    via_abi = hashlib.sha256(np.ascontiguousarray(np.array(sim.getPosition())).tobytes()).hexdigest()
+    sim.close()
+    ref = O.OracleSim(n, False)
+    ref.setup()
+    ref.step(100)
+    want = hashlib.sha256(np.ascontiguousarray(ref.download()["pos"]).tobytes()).hexdigest()
+    ref.close()
+    assert got == via_abi == want
+
+
+@pytest.mark.gpu
+def test_cli_headline_run_matches_the_oracles_step_100_checksum():
+    """`./sph -n 4194304 -i random -m time` -- the benchmark command line itself --
+    ends on the positions the CPU oracle computed (tests/golden, step 100)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "random4194304_sha256.json")))
+    r = run("-n", str(gold["n"]), "-i", "random", "-m", "time", env={"SPH_PRINT_SHA256": "1"})
+    assert r.returncode == 0, r.stderr
+    assert _sha_of(r.stdout) == gold["steps"]["100"]["pos_sha256"]
+
+
+@pytest.mark.gpu
+def test_cli_free_mode_with_click_matches_the_oracle():
+    """-m free (simulate() + the mouseClicked handshake, simulator.cu:482-489): 6 frames
+    with a click after frame 3, against the oracle doing the same."""
+    import hashlib
+
+    import numpy as np
+
+    from oracle import oracle as O
+
+    n = 20000
+    r = run("-n", str(n), "-i", "random", "-m", "free",
+            env={"SPH_FREE_FRAMES": "6", "SPH_FREE_CLICK": "1", "SPH_PRINT_SHA256": "1"})
+    assert r.returncode == 0, r.stderr
+    ref = O.OracleSim(n, True)
+    ref.setup()
+    for f in range(6):
+        ref.step()
+        if f == 3:  # headless.cpp sets mouseClicked before frame frames/2; simulate() applies it after the step
+            ref.click(400, 300)
+    want = hashlib.sha256(np.ascontiguousarray(ref.download()["pos"]).tobytes()).hexdigest()
+    ref.close()
+    assert _sha_of(r.stdout) == want

@@ -215,3 +215,36 @@ def test_hip_slab_reference_initialiser_4_slabs():
     sim.close()
     for sl in slabs:
         sl.b.close()
+
+
+@pytest.mark.gpu
+def test_hip_slab_config4_size_16M_particles_4_slabs():
+    """BASELINE config 4 at FULL size (-n 16777216 -i random, 4 z-slabs): the
+    decomposition (capacity per slab, not n; one-layer halos of ~210 K particles;
+    fixed-size exchange messages) against the single-domain HIP path, which the
+    headline checksums pin to the oracle.  Two steps, bit for bit."""
+    n, steps, world = 16777216, 2, 4
+    settings = sph.default_settings(n, True)
+    p4, v4 = S.make_initial(settings)
+    bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+    cap = int(max(len(p[0]) for p in parts) * 1.3) + 65536
+    face = min(S.default_face_cap(p4, settings.h, 100), cap)
+    slabs = []
+    for r, ((zlo, zhi), (pp, vv)) in enumerate(zip(bounds, parts)):
+        sl = S.Slab(S.HipSlabBackend(settings, cap, device=0), r, world, zlo, zhi, 100, face_cap=face)
+        sl.load(torch.from_numpy(pp).cuda(), torch.from_numpy(vv).cuda())
+        slabs.append(sl)
+    del parts
+    S.run_loopback(slabs, steps)
+    got = collect([tuple(x.cpu().numpy() for x in sl.owned()) for sl in slabs], n)
+    assert sum(sl.overflows for sl in slabs) == 0
+    for sl in slabs:
+        sl.b.close()
+    sim = sph.Simulator(settings)
+    sim.setup()
+    for _ in range(steps):
+        sim.simulate()
+    st = sim.download_state()
+    sim.close()
+    assert_bit_equal(got[0], st["pos"], "16.7M particles, 4 slabs vs single domain: pos")
+    assert_bit_equal(got[2], st["rho"], "16.7M particles, 4 slabs vs single domain: rho")
