@@ -24,8 +24,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 7.86e13    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 DENSITY_BYTES_PER_PARTICLE = 20  # read 12-B position, write rho + p
-DENSITY_LANEOPS_PER_TEST = 12    # SURVEY.md 8d convention
-FORCE_LANEOPS_PER_TEST = 55
+DENSITY_LANEOPS_PER_TEST = 12    # SURVEY.md 8d convention (per candidate pair test)
+FORCE_LANEOPS_PER_PAIR = 55      # SURVEY.md 8d convention (per evaluated pair body)
+FULL_RUN_STEPS = 100             # main.cpp:69: the -m time loop is 100 x simulateAndTime
 
 
 def parse():
@@ -46,6 +47,8 @@ def parse():
                     help="skip the secondary run of the reference's linked-list neighbour structure")
     ap.add_argument("--no-fast-leg", action="store_true",
                     help="skip the extra SPH_MATH_FAST measurement")
+    ap.add_argument("--no-count-replay", action="store_true",
+                    help="skip the untimed replay that counts pair tests / hits (valu_frac figures)")
     ap.add_argument("--cpu-steps", type=int, default=12,
                     help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-particles", type=int, default=0, help="0 = same n as the GPU run")
@@ -59,6 +62,7 @@ def cpu_baseline(n, random_init, steps):
     sizes are timed -- 16 threads and every reported core -- and the faster one is
     the baseline (`cores` = the threads of that run)."""
     from oracle import oracle as O
+    build = O.use_native_build()  # BASELINE.md section 3: -O3 -march=native -fopenmp, built on this host
 
     def run(threads):
         O.set_num_threads(threads)
@@ -74,10 +78,10 @@ def cpu_baseline(n, random_init, steps):
     legs = {t: run(t) for t in sorted({min(16, ncpu), ncpu})}
     threads, dt = min(legs.items(), key=lambda kv: kv[1])
     out = {"value": n * steps / dt, "unit": "particle-steps/s", "cores": threads,
-           "kind": "port",
+           "kind": "port", "steps": steps, "build": build,
            "sample": f"first {steps} steps of -n {n} -i {'random' if random_init else 'grid'} "
                      f"(of the 100-step run; later steps cost up to 4.7x more), "
-                     f"OpenMP oracle, {dt:.1f} s; team sizes tried: "
+                     f"OpenMP oracle ({build}), {dt:.1f} s; team sizes tried: "
                      + ", ".join(f"{t} threads {n * steps / d:.3g}/s" for t, d in legs.items())}
     # the same oracle on ONE core (bounded: the first step only)
     O.set_num_threads(1)
@@ -96,14 +100,18 @@ def cpu_baseline(n, random_init, steps):
 def load_traffic(n, args):
     """HBM bytes per computeDensity launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
-    command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for 16-B/lane
-    streaming reads).  None if no measurement matches this workload."""
+    command line; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for
+    16-B/lane streaming reads).  Work per launch grows over the run, so only a
+    measurement of the SAME step count K (and warm-up) is used: None otherwise --
+    windows are never mixed."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
     try:
         for e in json.load(open(path)):
-            if e["n"] == n and e["init"] == args.init and e["sweep"] == args.sweep and e["gpus"] == 1:
+            if (e["n"] == n and e["init"] == args.init and e["sweep"] == args.sweep and e["gpus"] == 1
+                    and e.get("math", "strict") == args.math and e.get("steps") == args.steps
+                    and e.get("warmup") == args.warmup):
                 return e
     except Exception:
         return None
@@ -152,8 +160,9 @@ def main():
         result = run_slab_bench(args, dist, rank, world, local_rank)
     else:
         s = sph.default_settings(n, random_init)
-        sim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank,
-                            math=args.math)
+        # the timed run carries no counting code at all (SPH_FLAG_COUNT_PAIRS adds atomics
+        # to the density sweep); pair tests and hits come from an untimed replay below
+        sim = sph.Simulator(s, sweep=args.sweep, flags=0, device=local_rank, math=args.math)
         sim.setup()
         times = sph.Times()
         for _ in range(W):
@@ -178,6 +187,18 @@ def main():
         if os.environ.get("SPH_STAMPS"):
             result["stamps"] = sim.debug_counters()
         sim.close()
+        if not args.no_count_replay:
+            # untimed replay of the same K steps with the counters on (the run is
+            # deterministic: same trajectory, same pair tests and hits per step)
+            csim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank,
+                                 math=args.math)
+            csim.setup()
+            for _ in range(K):
+                csim.simulate()
+            ckt = csim.kernel_times()
+            result["pair_tests"] = ckt.pair_tests / max(int(ckt.steps), 1)
+            result["pair_hits"] = ckt.pair_hits / max(int(ckt.steps), 1)
+            csim.close()
         if args.sweep == "list" and args.math == "strict" and not args.no_linked_leg:
             # secondary figure: the reference's own neighbour structure (per-cell
             # linked lists, no sort) on this GPU, same K steps (not `value`)
@@ -226,7 +247,7 @@ def main():
         dens_s = kt.density / steps      # avg launch duration of computeDensity (HIP events)
         force_s = kt.force / steps
         n_local = result.get("n_local", n)
-        pairs = kt.pair_tests / steps if kt.pair_tests else None
+        pairs = result.get("pair_tests") or None
         achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
         roof = {"bound": "hbm", "kernel": {"lds": "k_density_lds", "direct": "k_density_direct",
                                                    "linked": "k_density_linked",
@@ -238,9 +259,32 @@ def main():
         if pairs:
             roof["pair_tests_per_launch"] = pairs
             roof["valu_frac"] = pairs * DENSITY_LANEOPS_PER_TEST / dens_s / VALU_PEAK_LANEOPS
-            roof["force_valu_frac"] = pairs * FORCE_LANEOPS_PER_TEST / force_s / VALU_PEAK_LANEOPS
+            roof["valu_frac_note"] = (f"pair tests (counted on the GPU) x {DENSITY_LANEOPS_PER_TEST} lane-ops "
+                                      f"(SURVEY.md 8d convention) / launch time / {VALU_PEAK_LANEOPS:.3g} lane-ops/s "
+                                      "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz)")
+            hits = result.get("pair_hits") or 0
+            if args.sweep == "list" and hits:
+                # the list sweep evaluates the pair body for recorded hits only
+                roof["force_pair_bodies_per_launch"] = hits
+                roof["force_hit_fraction"] = hits / pairs
+                roof["force_valu_frac"] = hits * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
+                roof["force_valu_frac_note"] = (
+                    f"k_force_list: pair bodies actually evaluated (popcount of the hit masks, counted on "
+                    f"the GPU) x {FORCE_LANEOPS_PER_PAIR} lane-ops (SURVEY.md 8d convention) / launch time "
+                    f"/ VALU peak; the kernel is bound by its divergent gathers, not by VALU issue (DESIGN.md)")
+            elif args.sweep in ("lds", "direct"):
+                # these sweeps run the test for every candidate and the body under a mask
+                roof["force_valu_frac"] = pairs * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
+                roof["force_valu_frac_note"] = "every candidate priced at the body's 55 lane-ops (tested, body masked)"
+        full = K == FULL_RUN_STEPS
         out = {
-            "metric": "particle-steps/sec (100-step -m time)",
+            "metric": ("particle-steps/sec (100-step -m time)" if full else
+                       f"particle-steps/sec (first {K} of the 100 steps of -m time)"),
+            "full_run": full,
+            "full_run_note": None if full else (
+                f"steps 1..{K} only: work per step grows 4.7x over the 100 steps (pressure and floor "
+                "contact start at step ~45), so this is not the 100-step figure; see DESIGN.md / profiles/ "
+                "for the full run"),
             "value": result["n_total"] * K / elapsed,
             "unit": "particle-steps/s",
             "n_gpus": world, "steps": K, "warmup": W,
@@ -292,7 +336,11 @@ def main():
         tr = load_traffic(result["n_total"], args) if world == 1 else None
         if tr:
             roof["traffic"] = tr["bytes_per_launch"]
+            roof["traffic_steps"] = tr["steps"]
             roof["traffic_source"] = tr["source"]
+        else:
+            roof["traffic_note"] = ("no rocprofv3 PMC measurement of this exact command (n, init, sweep, math, "
+                                    "steps, warmup) under profiles/traffic.json")
         if "stamps" in result:
             out["debug_stamps"] = result["stamps"]
         if args.cpu_steps > 0 and world == 1:  # rank 0 at N=1 only

@@ -50,7 +50,7 @@ class SphOptions(C.Structure):
 class SphKernelTimes(C.Structure):
     _fields_ = [("hash", C.c_double), ("sort", C.c_double), ("gather", C.c_double),
                 ("density", C.c_double), ("force", C.c_double), ("readback", C.c_double),
-                ("pair_tests", C.c_uint64), ("steps", C.c_int64)]
+                ("pair_tests", C.c_uint64), ("steps", C.c_int64), ("pair_hits", C.c_uint64)]
 
 
 def library_path():

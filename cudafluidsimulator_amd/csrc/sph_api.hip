@@ -28,7 +28,9 @@ namespace {
 thread_local std::string g_create_error;
 
 constexpr int kEventRing = 64;
-constexpr int kCounterWords = 16 + 256 * 16; // [0] pair tests, then 256 shards of stamps
+constexpr int kCounterWords = 16 + 256 * 16; // 16 spare words, then 256 shards x 16: [0] pair tests,
+                                             // [1..13] in-kernel stamps (diagnostic builds), [15] hits
+constexpr size_t kCursorBytes = (size_t)SL_POOL_SHARDS * SL_CURSOR_STRIDE * sizeof(unsigned long long);
 
 struct PairEvent { // one timed section of the slab path
     hipEvent_t a = nullptr, b = nullptr;
@@ -245,8 +247,8 @@ int alloc_device(sph_handle *h) {
         const size_t hdrWords = 2 * ((cap + 63) / 64 + 1);
         HIPCHK(h, hipMalloc(&h->maskOff, hdrWords * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->maskOff, 0xFF, hdrWords * sizeof(uint32_t)));
-        HIPCHK(h, hipMalloc(&h->maskCursor, sizeof(unsigned long long)));
-        HIPCHK(h, hipMemset(h->maskCursor, 0, sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc(&h->maskCursor, kCursorBytes));
+        HIPCHK(h, hipMemset(h->maskCursor, 0, kCursorBytes));
     }
     HIPCHK(h, hipMalloc(&h->boundsDev, 16 * sizeof(int)));
     HIPCHK(h, hipHostMalloc(&h->boundsHost, 8 * sizeof(int), hipHostMallocDefault));
@@ -550,7 +552,7 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     A.force_out = nullptr;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
     PairEvent *pe = nullptr;
-    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, sizeof(unsigned long long), h->compute));
+    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, kCursorBytes, h->compute));
     if ((rc = pair_begin(h, &h->kt.density, &pe))) return rc;
     sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
     HIPCHK(h, hipEventRecord(pe->b, h->compute));
@@ -783,7 +785,7 @@ int sph_phase_density(sph_handle *h) {
     if (h->phase != 1) return fail(h, SPH_ESTATE, "density phase needs the grid phase first");
     SweepArgs A = make_sweep_args(h);
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
-    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, sizeof(unsigned long long), h->compute));
+    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, kCursorBytes, h->compute));
     sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
     if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->e[4], h->compute));
     HIPCHK(h, hipGetLastError());
@@ -1059,8 +1061,13 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     for (auto &pe : h->pairs)
         if ((rc = resolve_pair(h, pe))) return rc;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) {
-        HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        h->kt.pair_tests = *h->pairHost;
+        HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        h->kt.pair_tests = h->pairHost[0];
+        h->kt.pair_hits = 0;
+        for (int sh = 0; sh < 256; ++sh) { // sharded counters (one address would serialise the waves)
+            h->kt.pair_tests += h->pairHost[16 + sh * 16];
+            h->kt.pair_hits += h->pairHost[16 + sh * 16 + 15];
+        }
     }
     *out = h->kt;
     if (reset) {
@@ -1077,7 +1084,7 @@ int sph_debug_counters(sph_handle *h, uint64_t *out16) {
     HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 16; ++k) out16[k] = h->pairHost[k];
     for (int sh = 0; sh < 256; ++sh)
-        for (int k = 1; k < 16; ++k) out16[k] += h->pairHost[16 + sh * 16 + k];
+        for (int k = 0; k < 16; ++k) out16[k] += h->pairHost[16 + sh * 16 + k];
     return SPH_OK;
 }
 

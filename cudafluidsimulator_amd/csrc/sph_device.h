@@ -83,6 +83,11 @@ void sph_launch_copy_segments(const SegmentTable &T, float4 *dpos, float4 *dvel,
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4,
                       int mx, int my, hipStream_t s);
 
+// Hit-stream pool of the list sweep: cut into sub-pools with one allocation cursor each
+// (one cursor per 256 bytes), see k_density_mask_lds.
+#define SL_POOL_SHARDS 64
+#define SL_CURSOR_STRIDE 32 // unsigned long long per cursor slot
+
 // ---- sweeps (sweeps.hip) ----
 struct SweepArgs {
     const float4 *pos4;       // sorted positions (+id)
@@ -101,7 +106,7 @@ struct SweepArgs {
     // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
     uint32_t *maskPool;               // pool of quads: two (first candidate, 32-bit mask) pairs each
     uint32_t *maskOff;                // per 64-particle wave: {first quad or ~0u, quads per lane}
-    unsigned long long *maskCursor;   // quads handed out this step
+    unsigned long long *maskCursor;   // quads handed out this step, per sub-pool: [SL_POOL_SHARDS][SL_CURSOR_STRIDE]
     unsigned long long maskCapacity;  // pool size in quads
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams

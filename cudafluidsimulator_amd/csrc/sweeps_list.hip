@@ -20,6 +20,7 @@
 #include "sweep_common.h"
 
 #define SL_NONE 0xFFFFFFFFu
+// SL_POOL_SHARDS / SL_CURSOR_STRIDE live in sph_device.h (the host sizes the cursor array)
 
 // In-kernel phase stamps (diagnostic builds only: -DSW_STAMPS=1), as in sweeps.hip.
 #ifndef SW_STAMPS
@@ -132,19 +133,26 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
         pairs += (uint32_t)(je[r] - js[r]);
     }
     const int Q = __builtin_amdgcn_readfirstlane((wave_max_i32(words) + 1) >> 1); // quads per lane
+    // The pool is cut into SL_POOL_SHARDS equal sub-pools, each with its own cursor on a
+    // cache line of its own: 65,536 waves per launch bumping ONE address is a rate limit
+    // of its own (a returning atomic on one word saturates at ~88 per microsecond on this
+    // chip: 0.74 ms per launch, which is what bounded this kernel's early steps in round 1).
+    const int shard = wv & (SL_POOL_SHARDS - 1);
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(A.maskCursor, (unsigned long long)Q * SPH_WAVE);
+    if (lane == 0) base = atomicAdd(A.maskCursor + shard * SL_CURSOR_STRIDE, (unsigned long long)Q * SPH_WAVE);
     base = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32 |
            (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
-    const bool ok = base + (unsigned long long)Q * SPH_WAVE <= A.maskCapacity; // in quads; wave-uniform
+    const unsigned long long subCap = A.maskCapacity / SL_POOL_SHARDS;    // quads per sub-pool
+    const bool ok = base + (unsigned long long)Q * SPH_WAVE <= subCap;    // wave-uniform
+    base += (unsigned long long)shard * subCap;
     if (lane == 0 && i < A.i_end) {
         A.maskOff[2 * (size_t)wv] = ok ? (uint32_t)base : SL_NONE;
         A.maskOff[2 * (size_t)wv + 1] = (uint32_t)Q;
     }
     uint4 *const myq = reinterpret_cast<uint4 *>(A.maskPool) + (ok ? base : 0ull) + lane;
-    if (A.pairCounter) {
+    if (A.pairCounter) { // sharded like the stamps: one address would serialise the waves
         uint32_t s = wave_sum_u32(pairs);
-        if (lane == 0) atomicAdd(A.pairCounter, (unsigned long long)s);
+        if (lane == 0) atomicAdd(A.pairCounter + 16 + (wv & 255) * 16, (unsigned long long)s);
     }
 
     if (lane < SW_UNROLL) stage[SW_CAP + lane] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
@@ -533,6 +541,29 @@ void k_force_list(DevParams P, SweepArgs A) {
     }
 }
 
+// SPH_FLAG_COUNT_PAIRS only (bench.py's untimed counting replay): pair bodies the force
+// sweep will evaluate = set bits of the recorded masks.  A kernel of its own so that the
+// production kernels carry no counting code.
+__global__ __launch_bounds__(256) void k_count_hits(SweepArgs A) {
+    const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = 0;
+    if (i < A.i_end) {
+        const int wv = (i - A.i_begin) >> 6;
+        const uint32_t baseq = A.maskOff[2 * (size_t)wv];
+        const int Q = (int)A.maskOff[2 * (size_t)wv + 1];
+        if (baseq != SL_NONE) {
+            const uint4 *q4 = reinterpret_cast<const uint4 *>(A.maskPool) + baseq + (threadIdx.x & 63);
+            for (int q = 0; q < Q; ++q) {
+                const uint4 t = q4[(size_t)q * SPH_WAVE];
+                n += (uint32_t)__builtin_popcount(t.y) + (uint32_t)__builtin_popcount(t.w);
+                if (t.w == 0u) break;
+            }
+        }
+    }
+    n = wave_sum_u32(n);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(A.pairCounter + 16 + (blockIdx.x & 255) * 16 + 15, (unsigned long long)n);
+}
+
 void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
@@ -545,6 +576,7 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
         if (same) k_density_mask_lds<false, true><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
         else k_density_mask_lds<false, false><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);
     }
+    if (A.pairCounter) k_count_hits<<<(cnt + 255) / 256, 256, 0, s>>>(A);
 }
 
 // Particles whose wave found the mask pool exhausted in the density sweep: test

@@ -560,8 +560,7 @@ def run_slab_bench(args, dist, rank, world, local_rank):
     zlo, zhi = bounds[rank]
     my_pos, my_vel = parts[rank]
     cap = int(max(len(p[0]) for p in parts) * 1.6) + 65536
-    backend = HipSlabBackend(settings, cap, device=local_rank, sweep=args.sweep,
-                             flags=_lib.SPH_FLAG_COUNT_PAIRS)
+    backend = HipSlabBackend(settings, cap, device=local_rank, sweep=args.sweep, flags=0)
     slab = Slab(backend, rank, world, zlo, zhi, D, face_cap=min(default_face_cap(pos4, settings.h, D), cap))
     tr = DistTransport(dist, rank, world, backend.device, via_cpu=dist.get_backend() == "gloo")
     # Per-step position read-back (simulator.cu:479) of the owned particles, off the

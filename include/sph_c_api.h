@@ -96,6 +96,9 @@ typedef struct SphKernelTimes {
     double hash, sort, gather, density, force, readback;
     uint64_t pair_tests; /* sum over steps, if SPH_FLAG_COUNT_PAIRS */
     int64_t steps;
+    uint64_t pair_hits;  /* SPH_FLAG_COUNT_PAIRS + SPH_SWEEP_LIST: candidates inside the support
+                            radius = pair bodies the force sweep evaluates (popcount of the
+                            recorded hit masks), summed over steps; 0 for the other sweeps */
 } SphKernelTimes;
 
 typedef struct sph_handle sph_handle;

@@ -44,11 +44,24 @@ def build(force=False):
 _lib = None
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: switch this module to the -O3 -march=native build
+    of the same source (oracle/Makefile target `native`), compiled on THIS machine.
+    Must be called before the library is first used.  Returns the flags string."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("oracle library already loaded")
+    subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL)
+    _LIB_PATH = os.path.join(_HERE, "_native", "libsph_oracle_native.so")
+    return "gcc -O3 -march=native -ffp-contract=off -fno-fast-math -fopenmp"
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
+    if not _LIB_PATH.endswith("_native.so"):
+        build()
     # A GPU box hands a job a CPU *share* (about 16 cores of a 128-core host) that
     # neither os.cpu_count() nor the affinity mask shows.  A 128-thread OpenMP team
     # spinning at every barrier on that share can make a one-second test take minutes,

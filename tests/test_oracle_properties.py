@@ -58,6 +58,22 @@ def test_result_independent_of_thread_count():
     assert outs[0] == outs[1]
 
 
+def test_baseline_build_of_the_oracle_gives_identical_bits():
+    """bench.py times the -O3 -march=native build (oracle/Makefile `native`) as the CPU
+    baseline; same source, still no contraction / fast-math, so the same results."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import numpy as np; import hashlib;"
+            "from oracle import oracle as O; from helpers import dense_block;"
+            "NATIVE and O.use_native_build();"
+            "p=dense_block(14, jitter=0.003, seed=2); s=O.OracleSim(len(p), False); s.upload(p); s.step(6);"
+            "d=s.download(); print(hashlib.sha256(d['pos'].tobytes()+d['rho'].tobytes()).hexdigest())" %
+            (root, os.path.dirname(__file__)))
+    outs = [subprocess.check_output([sys.executable, "-c", code.replace("NATIVE", flag)]).strip()
+            for flag in ("False", "True")]
+    assert outs[0] == outs[1]
+
+
 def test_click_impulse_pushes_column():
     pos, vel = random_state(4000, 11, vmax=0.0)
     sim = O.OracleSim(len(pos), False)
