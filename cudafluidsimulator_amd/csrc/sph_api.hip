@@ -365,6 +365,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.maskCursor = h->maskCursor;
     A.maskCapacity = h->maskCapacity;
     A.pv8 = h->pv8;
+    A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
     A.listNext = reinterpret_cast<const int *>(h->ws.vals[0]);
     return A;

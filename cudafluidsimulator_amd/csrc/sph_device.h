@@ -109,6 +109,7 @@ struct SweepArgs {
     unsigned long long *maskCursor;   // quads handed out this step, per sub-pool: [SL_POOL_SHARDS][SL_CURSOR_STRIDE]
     unsigned long long maskCapacity;  // pool size in quads
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
+    int rhoToVel4;                    // list sweep: also store rho in vel4.w (slab halo exchange B)
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
     const int *listHead;              // [numCells] first particle of the cell or -1
     const int *listNext;              // [n] next particle of the same cell or -1

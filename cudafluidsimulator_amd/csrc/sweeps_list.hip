@@ -367,7 +367,9 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
     }
     if (valid) {
         rho = fmaxf(rho, SPH_EPS_F);
-        A.vel4[i].w = rho;
+        // the force sweep of this variant reads every record (its own too) from pv8; the
+        // separate velocity stream only needs rho when halo layers are exchanged (slabs)
+        if (A.rhoToVel4) A.vel4[i].w = rho;
         A.pv8[2 * (size_t)i + 1].w = rho;
     }
 #if SW_STAMPS
@@ -408,8 +410,8 @@ void k_force_list(DevParams P, SweepArgs A) {
     const int i = A.i_begin + tileIdx * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     const int iSafe = valid ? i : A.i_begin;
-    float4 pi = A.pos4[iSafe];
-    const float4 vi = A.vel4[iSafe];
+    float4 pi = A.pv8[2 * (size_t)iSafe];
+    const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
     const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
     // this wave's hit stream (layout: k_density_mask_lds): Q quads per lane, quad q of
     // this lane at stream4[q * 64] = two (first candidate, 32-bit hit mask) pairs
@@ -588,8 +590,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, Swee
     const bool mine = i < A.i_end && A.maskOff[2 * (size_t)((i - A.i_begin) >> 6)] == SL_NONE;
     if (!__ballot(mine)) return;
     const int iSafe = mine ? i : A.i_begin;
-    float4 pi = A.pos4[iSafe];
-    const float4 vi = A.vel4[iSafe];
+    float4 pi = A.pv8[2 * (size_t)iSafe];
+    const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
     const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
     int js[9], je[9];
@@ -598,8 +600,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, Swee
 #pragma unroll
     for (int r = 0; r < 9; ++r)
         for (int j = js[r]; j < je[r]; ++j) {
-            if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
-            else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+            if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pv8[2 * (size_t)j], A.pv8[2 * (size_t)j + 1], F);
+            else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pv8[2 * (size_t)j], A.pv8[2 * (size_t)j + 1], F);
         }
     if (mine) {
         float vx = vi.x, vy = vi.y, vz = vi.z;
