@@ -279,7 +279,10 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
                         } else {
                             dist2 = dx * dx + dy * dy + dz * dz;
                             draw = h2v - dist2;
-                            const float diff = fmaxf(draw, 0.f);
+                            // (fmaxf() of a value that is also used as bits costs a second,
+                            // canonicalising v_max: the difference of two finite floats needs none)
+                            float diff;
+                            asm("v_max_f32_e32 %0, 0, %1" : "=v"(diff) : "v"(draw));
                             rho += massv * (dcv * diff * diff * diff);
                         }
                         if (SAMECUT) { // m = 2m + (dist2 > h2): one op
