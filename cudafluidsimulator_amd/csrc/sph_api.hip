@@ -358,6 +358,8 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.stampCounter = (h->opt.flags & SPH_FLAG_COUNT_PAIRS) ? h->pairCounter : nullptr;
     A.i_begin = 0;
     A.i_end = h->n;
+    A.i_origin = 0;
+    A.patchHalo = 0;
     A.n_all = h->n;
     A.tileChunk = tile_chunk(h, h->n, h->zLayers);
     A.maskPool = h->maskPool;
@@ -442,13 +444,15 @@ int sph_bind_buffers(sph_handle *h, void *pos4_a, void *vel4_a, void *pos4_b, vo
     return SPH_OK;
 }
 
-int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
-                  const uint32_t *thresholds, int nthr, int32_t *bounds_out) {
+void *sph_get_stream(sph_handle *h) { return h ? (void *)h->compute : nullptr; }
+
+int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
+                        const uint32_t *thresholds, int nthr, void *bounds_dev_out) {
     if (!h) return SPH_EINVAL;
     int rc = slab_range_ok(h, src_buf, 0, 0, 0);
     if (rc) return rc;
     if (src_offset < 0 || count < 0 || (long long)src_offset + count > h->cap || nthr < 0 ||
-        nthr > 8 || (nthr > 0 && (!thresholds || !bounds_out)))
+        nthr > 8 || (nthr > 0 && !thresholds))
         return fail(h, SPH_EINVAL, "bad sort range");
     hipStream_t s = h->compute;
     PairEvent *pe = nullptr;
@@ -465,11 +469,10 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
     if (nthr > 0) {
         Thresholds T{};
         for (int k = 0; k < nthr; ++k) T.v[k] = thresholds[k];
-        sph_launch_lower_bounds(h->ws.keys[res], count, T, nthr, h->boundsDev, s);
-        HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int),
-                                 hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
-        for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
+        sph_launch_lower_bounds(h->ws.keys[res], count, T, nthr, h->boundsDev, s); // also [nthr] = count
+        if (bounds_dev_out)
+            HIPCHK(h, hipMemcpyAsync(bounds_dev_out, h->boundsDev, (nthr + 1) * sizeof(int),
+                                     hipMemcpyDeviceToDevice, s));
     }
     HIPCHK(h, hipGetLastError());
     h->sorted = src_buf ^ 1;
@@ -478,14 +481,28 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
     return SPH_OK;
 }
 
-int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
-                       const uint32_t *thresholds, int nthr, int32_t *bounds_out,
-                       void *bounds_dev_out) {
+int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
+                  const uint32_t *thresholds, int nthr, int32_t *bounds_out) {
+    if (!h) return SPH_EINVAL;
+    if (nthr > 0 && !bounds_out) return fail(h, SPH_EINVAL, "bad sort range");
+    int rc = sph_slab_sort_async(h, src_buf, src_offset, count, thresholds, nthr, nullptr);
+    if (rc) return rc;
+    if (nthr > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int),
+                                 hipMemcpyDeviceToHost, h->compute));
+        HIPCHK(h, hipStreamSynchronize(h->compute));
+        for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
+    }
+    return SPH_OK;
+}
+
+int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int count,
+                             const uint32_t *thresholds, int nthr, void *bounds_dev_out) {
     if (!h) return SPH_EINVAL;
     int rc = slab_range_ok(h, src_buf, 0, 0, 0);
     if (rc) return rc;
     if (src_offset < 0 || count < 0 || (long long)src_offset + count > h->cap || nthr < 1 ||
-        nthr > 8 || !thresholds || !bounds_out)
+        nthr > 8 || !thresholds)
         return fail(h, SPH_EINVAL, "bad partition range");
     for (int k = 1; k < nthr; ++k)
         if (thresholds[k] < thresholds[k - 1]) return fail(h, SPH_EINVAL, "thresholds must ascend");
@@ -500,18 +517,27 @@ int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
     sph_launch_gather_plain(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
                             h->ws.vals[res], h->pos4[src_buf ^ 1], h->vel4[src_buf ^ 1], count, s);
     HIPCHK(h, hipEventRecord(pe->b, s));
-    // bounds[k] = #particles with key < thresholds[k] = #classes <= k
     Thresholds C{};
     for (int k = 0; k < nthr; ++k) C.v[k] = (uint32_t)(k + 1);
     sph_launch_lower_bounds(h->ws.keys[res], count, C, nthr, h->boundsDev, s); // also [nthr] = count
-    if (bounds_dev_out) // the message header of the exchange, without a trip through the host
+    if (bounds_dev_out)
         HIPCHK(h, hipMemcpyAsync(bounds_dev_out, h->boundsDev, (nthr + 1) * sizeof(int),
                                  hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
     HIPCHK(h, hipGetLastError());
-    h->gridValid = false; // no cell table: sph_slab_sort builds it for the combined array
+    h->gridValid = false;
+    return SPH_OK;
+}
+
+int sph_slab_partition(sph_handle *h, int src_buf, int src_offset, int count,
+                       const uint32_t *thresholds, int nthr, int32_t *bounds_out,
+                       void *bounds_dev_out) {
+    if (!h) return SPH_EINVAL;
+    if (!bounds_out) return fail(h, SPH_EINVAL, "bad partition range");
+    int rc = sph_slab_partition_async(h, src_buf, src_offset, count, thresholds, nthr, bounds_dev_out);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->boundsHost, h->boundsDev, nthr * sizeof(int), hipMemcpyDeviceToHost, h->compute));
+    HIPCHK(h, hipStreamSynchronize(h->compute));
+    for (int k = 0; k < nthr; ++k) bounds_out[k] = h->boundsHost[k];
     return SPH_OK;
 }
 
@@ -548,6 +574,7 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     SweepArgs A = make_sweep_args(h);
     A.i_begin = i_begin;
     A.i_end = i_end;
+    A.i_origin = i_begin;
     A.n_all = n_all;
     A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
     A.force_out = nullptr;
@@ -569,6 +596,8 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     SweepArgs A = make_sweep_args(h);
     A.i_begin = i_begin;
     A.i_end = i_end;
+    A.i_origin = i_begin;
+    A.patchHalo = 1;
     A.n_all = n_all;
     A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
     A.force_out = nullptr;
@@ -578,6 +607,46 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     HIPCHK(h, hipEventRecord(pe->b, h->compute));
     HIPCHK(h, hipGetLastError());
     h->kt.steps += 1;
+    return SPH_OK;
+}
+
+int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
+    if (rc) return rc;
+    if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
+    if (h->opt.sweep != SPH_SWEEP_LIST) return SPH_OK; // the other sweeps read vel4 directly
+    SweepArgs A = make_sweep_args(h);
+    A.i_begin = i_begin;
+    A.i_end = i_end;
+    A.n_all = n_all;
+    sph_launch_patch_halo(A, h->compute);
+    HIPCHK(h, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_force_range(sph_handle *h, int buf, int i_origin, int a, int b, int n_all, int last) {
+    if (!h) return SPH_EINVAL;
+    int rc = slab_range_ok(h, buf, a, b, n_all);
+    if (rc) return rc;
+    if (i_origin < 0 || i_origin > a) return fail(h, SPH_EINVAL, "bad wave origin");
+    if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
+    if (b > a) {
+        SweepArgs A = make_sweep_args(h);
+        A.i_begin = a;
+        A.i_end = b;
+        A.i_origin = i_origin;
+        A.patchHalo = 0;
+        A.n_all = n_all;
+        A.tileChunk = tile_chunk(h, b - a, h->zLayers);
+        A.force_out = nullptr;
+        PairEvent *pe = nullptr;
+        if ((rc = pair_begin(h, &h->kt.force, &pe))) return rc;
+        sph_launch_force(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
+        HIPCHK(h, hipEventRecord(pe->b, h->compute));
+        HIPCHK(h, hipGetLastError());
+    }
+    if (last) h->kt.steps += 1;
     return SPH_OK;
 }
 

@@ -101,7 +101,10 @@ struct SweepArgs {
     unsigned long long *pairCounter; // optional (SPH_FLAG_COUNT_PAIRS)
     unsigned long long *stampCounter; // diagnostic builds only (same buffer)
     int i_begin, i_end;       // owned range (whole array for one domain)
+    int i_origin;             // list sweep: particle 0 of wave 0 of the hit stream (the density
+                              // sweep's i_begin); a force launch may cover a sub-range of it
     int n_all;
+    int patchHalo;            // list sweep force launch: copy the halo rows' vel4 into pv8 first
     int tileChunk;            // xcd_tile(): 256-particle tiles per chunk (1/8 z-layer), 0 = eighths
     // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
     uint32_t *maskPool;               // pool of quads: two (first candidate, 32-bit mask) pairs each
@@ -121,6 +124,7 @@ void sph_launch_density_linked(const DevParams &P, const SweepArgs &A, hipStream
 void sph_launch_force_linked(const DevParams &P, const SweepArgs &A, hipStream_t s);
 void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s);
 void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s);
+void sph_launch_patch_halo(const SweepArgs &A, hipStream_t s);
 void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode,
                         int sweep, hipStream_t s);
 void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode,

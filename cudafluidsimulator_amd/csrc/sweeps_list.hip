@@ -409,9 +409,13 @@ __launch_bounds__(SL_K2_THREADS, SL_K2_WAVES)
 __launch_bounds__(SL_K2_THREADS)
 #endif
 void k_force_list(DevParams P, SweepArgs A) {
-    const int tileIdx = xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K2_THREADS));
-    const int i = A.i_begin + tileIdx * blockDim.x + threadIdx.x;
-    const bool valid = i < A.i_end;
+    // wave w of the hit stream owns particles [i_origin + 64 w, +64); this launch covers
+    // the waves that intersect [i_begin, i_end) (a sub-range when the slab driver runs the
+    // interior while the halo densities are still in flight)
+    const int tileIdx = ((A.i_begin - A.i_origin) >> 6) / (SL_K2_THREADS / SPH_WAVE) +
+                        xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K2_THREADS));
+    const int i = A.i_origin + tileIdx * blockDim.x + threadIdx.x;
+    const bool valid = i >= A.i_begin && i < A.i_end;
     const int iSafe = valid ? i : A.i_begin;
     float4 pi = A.pv8[2 * (size_t)iSafe];
     const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
@@ -431,7 +435,7 @@ void k_force_list(DevParams P, SweepArgs A) {
     // ds_read_b128 instead of a 64-address global gather.
     __shared__ float4 winAll[SL_K2_THREADS / SPH_WAVE][2 * SL_WINDOW];
     float4 *win = winAll[threadIdx.x >> 6];
-    const int tile0 = A.i_begin + tileIdx * blockDim.x + (threadIdx.x & ~63);
+    const int tile0 = A.i_origin + tileIdx * blockDim.x + (threadIdx.x & ~63);
     const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
     {
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(256) void k_count_hits(SweepArgs A) {
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 0;
     if (i < A.i_end) {
-        const int wv = (i - A.i_begin) >> 6;
+        const int wv = (i - A.i_origin) >> 6;
         const uint32_t baseq = A.maskOff[2 * (size_t)wv];
         const int Q = (int)A.maskOff[2 * (size_t)wv + 1];
         if (baseq != SL_NONE) {
@@ -590,7 +594,7 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
 template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, SweepArgs A) {
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = i < A.i_end && A.maskOff[2 * (size_t)((i - A.i_begin) >> 6)] == SL_NONE;
+    const bool mine = i < A.i_end && A.maskOff[2 * (size_t)((i - A.i_origin) >> 6)] == SL_NONE;
     if (!__ballot(mine)) return;
     const int iSafe = mine ? i : A.i_begin;
     float4 pi = A.pv8[2 * (size_t)iSafe];
@@ -622,17 +626,27 @@ __global__ void k_patch_pv8(const float4 *__restrict__ vel4, float4 *__restrict_
     if (j < n_all) pv8[2 * (size_t)j + 1] = vel4[j];
 }
 
+// rows outside [i_begin, i_end) of the n_all sorted rows are halo rows (A.i_begin/i_end
+// = the OWNED range here, whatever sub-range the force launches cover)
+void sph_launch_patch_halo(const SweepArgs &A, hipStream_t s) {
+    const int halo = A.i_begin + (A.n_all - A.i_end);
+    if (halo > 0) k_patch_pv8<<<(halo + 255) / 256, 256, 0, s>>>(A.vel4, A.pv8, A.i_begin, A.i_end, A.n_all);
+}
+
 void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-    const int halo = A.i_begin + (A.n_all - A.i_end);
-    if (halo > 0) k_patch_pv8<<<(halo + 255) / 256, 256, 0, s>>>(A.vel4, A.pv8, A.i_begin, A.i_end, A.n_all);
+    if (A.patchHalo) sph_launch_patch_halo(A, s);
+    // waves of the stream (numbered from i_origin) that hold particles of [i_begin, i_end)
+    const int w0 = (A.i_begin - A.i_origin) >> 6, w1 = (A.i_end - A.i_origin + 63) >> 6;
+    const int wpb = SL_K2_THREADS / SPH_WAVE;
+    const int fblocks = (w1 + wpb - 1) / wpb - w0 / wpb;
     if (mathMode == 1) {
-        k_force_list<true><<<(cnt + SL_K2_THREADS - 1) / SL_K2_THREADS, SL_K2_THREADS, 0, s>>>(P, A);
+        k_force_list<true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, A);
         k_force_fallback<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
     } else {
-        k_force_list<false><<<(cnt + SL_K2_THREADS - 1) / SL_K2_THREADS, SL_K2_THREADS, 0, s>>>(P, A);
+        k_force_list<false><<<fblocks, SL_K2_THREADS, 0, s>>>(P, A);
         k_force_fallback<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
     }
 }

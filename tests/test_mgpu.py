@@ -1,0 +1,170 @@
+"""The in-process C++ multi-GPU driver (libsph_mgpu.so, include/sph_mgpu.h): N z-slabs must
+reproduce the single-domain result BIT FOR BIT.  A one-GPU box can only run the loopback
+transport (N slabs on one device, device-to-device copies) and RCCL with one rank sending
+to itself; both go through the same step logic as the real multi-GPU transport."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cudafluidsimulator_amd as sph
+from cudafluidsimulator_amd import mgpu as M
+from helpers import assert_bit_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sph_mgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sph_mgpu_[a-z_]+)\s*\(", text)))
+
+
+def test_mgpu_library_exports_every_declared_symbol():
+    assert declared_symbols() == sorted(M.EXPORTED_SYMBOLS)
+    L = M.load_mgpu_library()
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", M.library_path()], text=True)
+    assert set(declared_symbols()) <= set(re.findall(r" T (sph_mgpu_\w+)", out))
+    assert C.sizeof(M.SphMgpuOptions) == 4 * (5 + 8 + 5)
+    # the host logic links RCCL and the kernel library, never the oracle
+    deps = subprocess.check_output(["ldd", M.library_path()], text=True)
+    assert "librccl" in deps and "libsph_hip" in deps and "oracle" not in deps
+
+
+def test_mgpu_without_a_gpu_fails_loudly(have_gpu):
+    if have_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(sph.SphError, match="no HIP device"):
+        M.MultiGpuSimulator(sph.default_settings(64, False), world=2, transport="loopback")
+
+
+def moving_state(n, seed, vz=9.0):
+    """Random fluid whose z-velocities move particles between slabs every step."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(0.5, 9.5, (n, 3)).astype(np.float32)
+    vel = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    vel[:, 2] = rng.uniform(-vz, vz, n).astype(np.float32)
+    return pos, vel
+
+
+def single_domain(settings, pos, vel, steps, sweep="list"):
+    sim = sph.Simulator(settings, sweep=sweep)
+    if pos is None:
+        sim.setup()
+    else:
+        sim.upload_state(pos, vel)
+    for _ in range(steps):
+        sim.simulate()
+    st = sim.download_state()
+    got = np.array(sim.getPosition(), copy=True)
+    sim.close()
+    return st, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,transport", [(2, "loopback"), (4, "loopback"), (8, "loopback"), (3, "rccl_self")])
+def test_slabs_equal_single_domain(world, transport):
+    n, steps = 80000, 8
+    pos, vel = moving_state(n, 5)
+    settings = sph.default_settings(n, False)
+    want, want_pos = single_domain(settings, pos, vel, steps)
+    mg = M.MultiGpuSimulator(settings, world=world, transport=transport)
+    mg.upload_state(pos, vel)
+    for _ in range(steps):
+        mg.simulate()
+    got = mg.download_state()
+    assert got["written"] == n
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    assert_bit_equal(got["vel"], want["vel"], "vel")
+    assert_bit_equal(got["rho"], want["rho"], "rho")
+    assert_bit_equal(np.array(mg.getPosition()), want_pos, "getPosition()")
+    st = mg.stats()
+    assert st.steps == steps and st.host_syncs == steps, "one host synchronisation per step"
+    assert sum(st.owned[:world]) == n
+    mg.close()
+
+
+@pytest.mark.gpu
+def test_two_layer_hops_and_tiny_faces():
+    """z-velocities up to 2.5 cells per step: migrants land beyond the neighbour's first
+    layer (the headers carry the near/far split); faces far too small for the traffic, so
+    the exact-size second round carries most of it."""
+    n, steps, world = 60000, 6, 3
+    pos, vel = moving_state(n, 11, vz=25.0)
+    settings = sph.default_settings(n, False)
+    want, _ = single_domain(settings, pos, vel, steps)
+    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback", face_capacity=300)
+    mg.upload_state(pos, vel)
+    for _ in range(steps):
+        mg.simulate()
+    got = mg.download_state()
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    assert_bit_equal(got["rho"], want["rho"], "rho")
+    assert mg.stats().overflow_rounds == steps
+    mg.close()
+
+
+@pytest.mark.gpu
+def test_hop_beyond_a_whole_slab_is_reported():
+    """A particle that crosses more of the neighbour slab than the decomposition allows
+    must end the run with an error, never a silently wrong result."""
+    n, world = 40000, 8
+    pos, vel = moving_state(n, 3, vz=1.0)
+    vel[:50, 2] = 1500.0      # 15 cells per step: through a whole 12-layer slab
+    pos[:50, 2] = 1.0
+    settings = sph.default_settings(n, False)
+    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback")
+    mg.upload_state(pos, vel)
+    with pytest.raises(sph.SphError, match="crossed|neighbour|above|below"):
+        for _ in range(4):
+            mg.simulate()
+        mg.sync()
+    mg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep", ["list", "lds"])
+def test_reference_initialiser_and_recut(sweep):
+    """-i random through 4 slabs with the cuts re-balanced every 3 steps (a re-cut is a
+    stable filter of the rank-concatenated sequence, so it keeps the canonical order)."""
+    n, steps, world = 262144, 7, 4
+    settings = sph.default_settings(n, True)
+    want, _ = single_domain(settings, None, None, steps, sweep=sweep)
+    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback", sweep=sweep, recut_every=3)
+    mg.setup()
+    t = sph.Times()
+    for _ in range(steps):
+        mg.simulateAndTime(t)
+    got = mg.download_state()
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    assert_bit_equal(got["vel"], want["vel"], "vel")
+    assert t.iters == steps and t.sphUpdate > 0
+    mg.close()
+
+
+@pytest.mark.gpu
+def test_sinking_fluid_recut_moves_the_cuts():
+    """Mass that drifts along z makes the static cuts lopsided; the re-cut follows it."""
+    n, world = 60000, 4
+    rng = np.random.default_rng(2)
+    pos = rng.uniform(1.0, 9.0, (n, 3)).astype(np.float32)
+    vel = np.zeros((n, 3), np.float32)
+    vel[:, 2] = 6.0           # everything drifts towards +z, 0.6 cells per step
+    settings = sph.default_settings(n, False)
+    want, _ = single_domain(settings, pos, vel, 12)
+    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback", recut_every=4)
+    mg.upload_state(pos, vel)
+    for _ in range(12):
+        mg.simulate()
+    got = mg.download_state()
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    st = mg.stats()
+    assert st.recuts >= 1
+    owned = list(st.owned[:world])
+    assert max(owned) - min(owned) < 0.25 * n / world, owned
+    mg.close()
