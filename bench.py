@@ -47,6 +47,10 @@ def parse():
                     help="skip the secondary run of the reference's linked-list neighbour structure")
     ap.add_argument("--no-fast-leg", action="store_true",
                     help="skip the extra SPH_MATH_FAST measurement")
+    ap.add_argument("--loopback-slabs", type=int, default=0,
+                    help="N > 1: step the domain as N z-slabs on ONE GPU through the C++ multi-GPU driver's "
+                         "loopback transport (what the decomposition costs per slab; never `value` of a "
+                         "multi-GPU run)")
     ap.add_argument("--no-count-replay", action="store_true",
                     help="skip the untimed replay that counts pair tests / hits (valu_frac figures)")
     ap.add_argument("--cpu-steps", type=int, default=12,
@@ -94,6 +98,62 @@ def cpu_baseline(n, random_init, steps):
     O.set_num_threads(threads)
     out["single_thread"] = {"value": n / dt1, "unit": "particle-steps/s", "cores": 1,
                             "sample": f"first step only, {dt1:.1f} s"}
+    return out
+
+
+def run_mgpu_bench(args, dist, rank, world, local_rank):
+    """N > 1: the C++ in-process driver (libsph_mgpu.so), one process per GPU: each rank
+    drives ONE z-slab; the halo layers travel by ncclSend/ncclRecv between the ranks' own
+    RCCL communicator (unique id made on rank 0, handed out through torch.distributed).
+    --loopback-slabs N: one process, N slabs on one GPU, device-to-device copies."""
+    import torch
+    import cudafluidsimulator_amd as sph
+    from cudafluidsimulator_amd import mgpu as M
+    n = args.particles
+    settings = sph.default_settings(n, args.init == "random")
+    if dist is not None:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(M.unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, src=0)
+        mg = M.MultiGpuSimulator(settings, world=world, rank=rank, devices=[local_rank],
+                                 unique_id=bytes(uid.cpu().tolist()), transport="rccl", sweep=args.sweep,
+                                 math=args.math)
+    else:
+        mg = M.MultiGpuSimulator(settings, world=args.loopback_slabs, transport="loopback",
+                                 devices=[local_rank], sweep=args.sweep, math=args.math)
+    mg.setup()
+    times = sph.Times()
+    # at least one untimed step: the first exchange builds the RCCL channels
+    for _ in range(max(args.warmup, 1)):
+        mg.simulateAndTime(times) if args.mode == "time" else mg.simulate()
+    mg.sync()
+    mg.setup()
+    mg.stats(reset=True)
+    times = sph.Times()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mg.simulateAndTime(times) if args.mode == "time" else mg.simulate()
+    mg.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    st = mg.stats()
+    local = st.local_slabs
+    from cudafluidsimulator_amd import SphKernelTimes
+    kt = SphKernelTimes()   # slab 0 of this process stands for the rank in the roofline figures
+    kt.sort, kt.density, kt.force, kt.steps = st.grid_s[0], st.density_s[0], st.force_s[0], st.steps
+    out = dict(elapsed=elapsed, n_total=n, n_local=int(st.owned[0]), times=times, kt=kt,
+               mgpu=dict(slabs=args.loopback_slabs if dist is None else world,
+                         host_syncs_per_step=st.host_syncs / max(st.steps, 1),
+                         overflow_rounds=int(st.overflow_rounds),
+                         kernel_ms_per_step_per_slab=[st.kernel_s[k] / max(st.steps, 1) * 1e3 for k in range(local)],
+                         owned=[int(st.owned[k]) for k in range(local)]))
+    mg.close()
     return out
 
 
@@ -155,9 +215,11 @@ def main():
     random_init = args.init == "random"
     K, W = args.steps, args.warmup
 
-    if world > 1:
-        from cudafluidsimulator_amd.slab import run_slab_bench
+    if world > 1 and os.environ.get("SPH_BENCH_SINGLE_DEVICE"):
+        from cudafluidsimulator_amd.slab import run_slab_bench   # gloo rehearsal of the Python driver
         result = run_slab_bench(args, dist, rank, world, local_rank)
+    elif world > 1 or args.loopback_slabs > 1:
+        result = run_mgpu_bench(args, dist if world > 1 else None, rank, world, local_rank)
     else:
         s = sph.default_settings(n, random_init)
         # the timed run carries no counting code at all (SPH_FLAG_COUNT_PAIRS adds atomics
@@ -242,7 +304,10 @@ def main():
 
     if rank == 0:
         elapsed = result["elapsed"]
-        kt = result["kt"]
+        kt = result.get("kt")
+        if kt is None:  # the C++ multi-GPU driver reports per-slab kernel time only
+            from cudafluidsimulator_amd import SphKernelTimes
+            kt = SphKernelTimes()
         steps = max(int(kt.steps), 1)
         dens_s = kt.density / steps      # avg launch duration of computeDensity (HIP events)
         force_s = kt.force / steps
@@ -300,7 +365,7 @@ def main():
                                       else "FAST fp32 math (FMA, approximate rcp/rsq; 1e-5 tolerance mode)"),
                        "sweep": args.sweep,
                        "parallelism": "single domain" if world == 1 else
-                       (f"z-slabs x{world} + RCCL halo" if not os.environ.get("SPH_BENCH_SINGLE_DEVICE")
+                       (f"z-slabs x{world}, one process per GPU, C++ driver + RCCL send/recv halo" if not os.environ.get("SPH_BENCH_SINGLE_DEVICE")
                         else f"REHEARSAL: z-slabs x{world} on ONE GPU, gloo via host")},
             "roofline": roof,
             "kernel_ms_per_step": {"hash": kt.hash / steps * 1e3, "sort": kt.sort / steps * 1e3,
@@ -343,6 +408,12 @@ def main():
                                     "steps, warmup) under profiles/traffic.json")
         if "stamps" in result:
             out["debug_stamps"] = result["stamps"]
+        if "mgpu" in result:
+            out["multi_gpu_driver"] = dict(result["mgpu"], host="C++ in-process driver (libsph_mgpu.so), "
+                                           + ("one process per GPU, ncclSend/ncclRecv halo exchange" if world > 1
+                                              else "LOOPBACK: N slabs on one GPU, device-to-device copies"))
+            if world == 1:
+                out["config"]["parallelism"] = f"LOOPBACK: {args.loopback_slabs} z-slabs on ONE GPU (decomposition cost study)"
         if args.cpu_steps > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_particles or n, random_init, args.cpu_steps)
         sys.stdout.flush()

@@ -28,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -60,8 +62,9 @@ struct Slab {
     sph_handle *h = nullptr;
     hipStream_t s = nullptr;      // compute (owned by h unless shared)
     hipStream_t comm = nullptr;   // exchange B overlaps the interior force sweep
+    hipStream_t bnd = nullptr;    // the boundary layers' force sweep (joins the interior's launch)
     hipStream_t copy = nullptr;   // position read-back
-    hipEvent_t evDensity = nullptr, evB = nullptr, evForce = nullptr, evCopy = nullptr;
+    hipEvent_t evDensity = nullptr, evB = nullptr, evBnd = nullptr, evForce = nullptr, evCopy = nullptr;
     hipEvent_t evT[3] = {nullptr, nullptr, nullptr}; // step start, grid done, force done
     F4 *pos[2] = {nullptr, nullptr}, *vel[2] = {nullptr, nullptr};
     F4 *rx_pos[2] = {nullptr, nullptr}, *rx_vel[2] = {nullptr, nullptr}; // [0] from below, [1] from above
@@ -101,6 +104,10 @@ struct sph_mgpu {
     long long step = 0;
     SphMgpuStats stats{};
     std::string err;
+    // step state carried between the phases of one step
+    std::chrono::steady_clock::time_point t_begin;
+    bool overflow = false;
+    int phase = 0;                 // phases of the current step already done (0..3)
 };
 
 namespace {
@@ -230,7 +237,18 @@ Slab *local(sph_mgpu *m, int rank) {
     return nullptr;
 }
 
-// One message of a round: `rows` float4 (or the 8-int header when rows < 0).
+// SPH_TRANSPORT_MAILBOX (tests): several one-slab driver objects inside ONE process stand for
+// the ranks of a one-process-per-GPU run; a send is a note in this table, the receive copies
+// from it once the sending object has posted (the test steps every object phase by phase).
+struct Mail { const void *src; size_t bytes; };
+std::map<std::pair<int, int>, std::deque<Mail>> g_mail;
+// receives of ALL objects waiting for the next phase: they are completed together, by
+// whichever object enters the next phase first -- like RCCL, where a send has left the
+// sender's buffer before any later kernel of the sender runs
+struct PendingRecv { int src_rank, dst_rank; void *dst; size_t bytes; hipStream_t stream; long long epoch; };
+std::vector<PendingRecv> g_pending;
+
+// One message of a round.
 struct Msg {
     int src_rank, dst_rank;
     const void *src; // valid if the sender is local
@@ -243,6 +261,15 @@ struct Msg {
 int deliver(sph_mgpu *m, const std::vector<Msg> &msgs, bool on_comm_stream) {
     if (msgs.empty()) return SPH_OK;
     const int tr = m->opt.transport;
+    if (tr == SPH_TRANSPORT_MAILBOX) {
+        for (const Msg &g : msgs) {
+            if (!g.bytes) continue;
+            if (local(m, g.src_rank)) g_mail[{g.src_rank, g.dst_rank}].push_back({g.src, g.bytes});
+            if (local(m, g.dst_rank))
+                g_pending.push_back({g.src_rank, g.dst_rank, g.dst, g.bytes, m->shared, m->step * 4 + m->phase});
+        }
+        return SPH_OK;
+    }
     if (tr == SPH_TRANSPORT_LOOPBACK) {
         for (const Msg &g : msgs) {
             if (!g.src || !g.dst) return fail(m, SPH_ESTATE, "loopback transport needs every slab in this process");
@@ -275,6 +302,29 @@ int deliver(sph_mgpu *m, const std::vector<Msg> &msgs, bool on_comm_stream) {
     return SPH_OK;
 }
 
+// mailbox transport: complete the receives posted in the previous phase
+int resolve_mail(sph_mgpu *m) {
+    if (m->opt.transport != SPH_TRANSPORT_MAILBOX || g_pending.empty()) return SPH_OK;
+    HIPM(m, hipDeviceSynchronize()); // the senders' data is complete (all objects share the device)
+    const long long now = m->step * 4 + m->phase; // receives posted in EARLIER phases only
+    std::vector<PendingRecv> later;
+    for (const auto &r : g_pending) {
+        if (r.epoch >= now) {
+            later.push_back(r);
+            continue;
+        }
+        auto &q = g_mail[{r.src_rank, r.dst_rank}];
+        if (q.empty()) return fail(m, SPH_ESTATE, "mailbox: the sending rank has not run this phase yet");
+        const Mail mm = q.front();
+        q.pop_front();
+        if (mm.bytes != r.bytes) return fail(m, SPH_ESTATE, "mailbox: sender and receiver disagree on a message size");
+        HIPM(m, hipMemcpyAsync(r.dst, mm.src, r.bytes, hipMemcpyDeviceToDevice, r.stream));
+    }
+    g_pending.swap(later);
+    HIPM(m, hipDeviceSynchronize());
+    return SPH_OK;
+}
+
 int free_slab(Slab &sl) {
     (void)hipSetDevice(sl.device);
     if (sl.h) sph_destroy(sl.h);
@@ -291,9 +341,10 @@ int free_slab(Slab &sl) {
     if (sl.sortb) (void)hipFree(sl.sortb);
     if (sl.pinned) (void)hipHostFree(sl.pinned);
     if (sl.hostRows) (void)hipHostFree(sl.hostRows);
-    for (hipEvent_t e : {sl.evDensity, sl.evB, sl.evForce, sl.evCopy, sl.evT[0], sl.evT[1], sl.evT[2]})
+    for (hipEvent_t e : {sl.evDensity, sl.evB, sl.evBnd, sl.evForce, sl.evCopy, sl.evT[0], sl.evT[1], sl.evT[2]})
         if (e) (void)hipEventDestroy(e);
     if (sl.comm) (void)hipStreamDestroy(sl.comm);
+    if (sl.bnd) (void)hipStreamDestroy(sl.bnd);
     if (sl.copy) (void)hipStreamDestroy(sl.copy);
     sl = Slab{};
     return SPH_OK;
@@ -329,7 +380,7 @@ int alloc_slab(sph_mgpu *m, Slab &sl) {
     HIPM(m, hipHostMalloc(&sl.pinned, 32 * sizeof(int), hipHostMallocDefault));
     memset(sl.pinned, 0, 32 * sizeof(int));
     HIPM(m, hipHostMalloc(&sl.hostRows, rows * sizeof(F4), hipHostMallocDefault));
-    for (hipEvent_t *e : {&sl.evDensity, &sl.evB, &sl.evForce, &sl.evCopy})
+    for (hipEvent_t *e : {&sl.evDensity, &sl.evB, &sl.evBnd, &sl.evForce, &sl.evCopy})
         HIPM(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (auto &e : sl.evT) HIPM(m, hipEventCreate(&e));
     HIPM(m, hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
@@ -340,6 +391,7 @@ int alloc_slab(sph_mgpu *m, Slab &sl) {
     } else {
         sl.s = (hipStream_t)sph_get_stream(sl.h);
         HIPM(m, hipStreamCreateWithFlags(&sl.comm, hipStreamNonBlocking));
+        HIPM(m, hipStreamCreateWithFlags(&sl.bnd, hipStreamNonBlocking));
     }
     HIPM(m, hipDeviceSynchronize());
     return SPH_OK;
@@ -496,10 +548,12 @@ int sph_mgpu_create(const SphSettings *settings, const SphMgpuOptions *options, 
     if (o.world < 1 || o.rank_count < 1 || o.rank_count > SPH_MGPU_MAX_LOCAL || o.rank_begin < 0 ||
         o.rank_begin + o.rank_count > o.world)
         return fail(nullptr, SPH_EINVAL, "bad world / rank range");
-    if (o.transport < SPH_TRANSPORT_LOOPBACK || o.transport > SPH_TRANSPORT_RCCL_SELF)
+    if (o.transport < SPH_TRANSPORT_LOOPBACK || o.transport > SPH_TRANSPORT_MAILBOX)
         return fail(nullptr, SPH_EINVAL, "unknown transport");
-    if (o.transport != SPH_TRANSPORT_RCCL && o.rank_count != o.world)
+    if ((o.transport == SPH_TRANSPORT_LOOPBACK || o.transport == SPH_TRANSPORT_RCCL_SELF) && o.rank_count != o.world)
         return fail(nullptr, SPH_EINVAL, "loopback / self transports need every slab in this process");
+    if (o.transport == SPH_TRANSPORT_MAILBOX && o.rank_count != 1)
+        return fail(nullptr, SPH_EINVAL, "mailbox transport: one slab per driver object");
     if (o.transport == SPH_TRANSPORT_RCCL && o.rank_count != o.world && (o.rank_count != 1 || !unique_id128))
         return fail(nullptr, SPH_EINVAL, "one process per GPU: rank_count = 1 and a unique id");
     if (o.sweep != SPH_SWEEP_LIST && o.sweep != SPH_SWEEP_LDS && o.sweep != SPH_SWEEP_DIRECT)
@@ -596,11 +650,15 @@ int sph_mgpu_upload_state(sph_mgpu *m, const float *pos_xyz, const float *vel_xy
     return upload_common(m, pos_xyz, vel_xyz, n);
 }
 
-int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
-    if (!m) return SPH_EINVAL;
-    if (!m->ready) return fail(m, SPH_ESTATE, "setup()/upload_state() must come first");
+} // extern "C"
+
+namespace {
+
+// A step in four phases; between two phases every message posted so far has been handed
+// to the transport (RCCL / copies: at once; mailbox: completed at the start of the next).
+int step_phase1(sph_mgpu *m, SphTimes *times) {
     const int F = m->F, DD = m->DD;
-    auto t_begin = std::chrono::steady_clock::now();
+    m->t_begin = std::chrono::steady_clock::now();
 
     // ---- 1. partition the owned rows by the z-range of their NEW cell (no host round trip)
     for (auto &sl : m->slabs) {
@@ -636,6 +694,13 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
         int rc = deliver(m, msgs, false);
         if (rc) return rc;
     }
+    return SPH_OK;
+}
+
+int step_phase2(sph_mgpu *m) {
+    const int F = m->F;
+    int rc0 = resolve_mail(m);
+    if (rc0) return rc0;
     // ---- 3. the step's ONE host synchronisation: own bounds + the neighbours' headers
     for (auto &sl : m->slabs) {
         HIPM(m, hipSetDevice(sl.device));
@@ -647,6 +712,7 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
     }
     m->stats.host_syncs++;
     bool overflow = false;
+    m->overflow = false;
     for (auto &sl : m->slabs) {
         memcpy(&sl.mine, sl.pinned, sizeof(Hdr));
         memcpy(&sl.nb_dn, sl.pinned + 8, sizeof(Hdr));
@@ -675,6 +741,7 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
     }
     // ---- 3b. (rare) a face outgrew its fixed-size message: exact-size second round
     if (overflow) {
+        m->overflow = true;
         m->stats.overflow_rounds++;
         std::vector<Msg> msgs;
         for (auto &sl : m->slabs) {
@@ -704,6 +771,13 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
         int rc = deliver(m, msgs, false);
         if (rc) return rc;
     }
+    return SPH_OK;
+}
+
+int step_phase3(sph_mgpu *m, SphTimes *times) {
+    const int DD = m->DD;
+    int rc0 = resolve_mail(m);
+    if (rc0) return rc0;
     // ---- 4. assemble, sort, density
     for (auto &sl : m->slabs) {
         HIPM(m, hipSetDevice(sl.device));
@@ -804,15 +878,28 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
         for (auto &sl : m->slabs)
             if (sl.comm) { HIPM(m, hipSetDevice(sl.device)); HIPM(m, hipEventRecord(sl.evB, sl.comm)); }
     }
+    return SPH_OK;
+}
+
+int step_phase4(sph_mgpu *m, SphTimes *times) {
+    int rc0 = resolve_mail(m);
+    if (rc0) return rc0;
     for (auto &sl : m->slabs) {
         HIPM(m, hipSetDevice(sl.device));
         const int a = sl.has_dn ? sl.e_lo : sl.i0, b = sl.has_up ? sl.s_hi : sl.i1;
         // interior layers: every neighbour is an owned row -> no need to wait for exchange B
-        SPHM(m, sl, sph_slab_force_range(sl.h, sl.sbuf, sl.i0, a, b, sl.n_comb, 0));
-        if (sl.comm) HIPM(m, hipStreamWaitEvent(sl.s, sl.evB, 0));
-        SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb));
-        SPHM(m, sl, sph_slab_force_range(sl.h, sl.sbuf, sl.i0, sl.i0, a, sl.n_comb, 0));
-        SPHM(m, sl, sph_slab_force_range(sl.h, sl.sbuf, sl.i0, b, sl.i1, sl.n_comb, 1));
+        SPHM(m, sl, sph_slab_force_ranges(sl.h, sl.sbuf, sl.i0, a, b, 0, 0, sl.n_comb, 0, nullptr));
+        // the two boundary layers in ONE launch once the halo densities are in: on a stream
+        // of their own they join the interior's launch on the GPU instead of waiting for its
+        // tail (with a shared stream -- loopback -- they simply follow it)
+        hipStream_t bs = sl.bnd ? sl.bnd : sl.s;
+        if (sl.bnd) HIPM(m, hipStreamWaitEvent(sl.bnd, sl.evB, 0));
+        SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb, bs));
+        SPHM(m, sl, sph_slab_force_ranges(sl.h, sl.sbuf, sl.i0, sl.i0, a, b, sl.i1, sl.n_comb, 1, bs));
+        if (sl.bnd) {
+            HIPM(m, hipEventRecord(sl.evBnd, sl.bnd));
+            HIPM(m, hipStreamWaitEvent(sl.s, sl.evBnd, 0));
+        }
         if (times) HIPM(m, hipEventRecord(sl.evT[2], sl.s));
         sl.cur = sl.sbuf ^ 1;
         sl.off = sl.i0;
@@ -843,12 +930,38 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
         }
         times->buildGrid += grid;
         times->sphUpdate += sphu;
-        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - m->t_begin).count();
         times->memcpy += std::max(0.0, wall - grid - sphu); // host-visible rest: exchange waits + sync
         times->iters += 1;
     }
     if (m->opt.recut_every > 0 && m->step % m->opt.recut_every == 0) {
         int rc = recut(m);
+        if (rc) return rc;
+    }
+    return SPH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sph_mgpu_step_phase(sph_mgpu *m, int phase, SphTimes *times) {
+    if (!m) return SPH_EINVAL;
+    if (!m->ready) return fail(m, SPH_ESTATE, "setup()/upload_state() must come first");
+    if (phase < 1 || phase > 4 || phase != m->phase + 1) return fail(m, SPH_ESTATE, "step phases run 1, 2, 3, 4");
+    int rc = phase == 1 ? step_phase1(m, times) : phase == 2 ? step_phase2(m)
+             : phase == 3 ? step_phase3(m, times) : step_phase4(m, times);
+    if (rc) return rc;
+    m->phase = phase == 4 ? 0 : phase;
+    return SPH_OK;
+}
+
+int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
+    if (!m) return SPH_EINVAL;
+    if (m->opt.transport == SPH_TRANSPORT_MAILBOX)
+        return fail(m, SPH_ESTATE, "mailbox transport: drive every rank's object with sph_mgpu_step_phase");
+    for (int ph = 1; ph <= 4; ++ph) {
+        int rc = sph_mgpu_step_phase(m, ph, times);
         if (rc) return rc;
     }
     return SPH_OK;
@@ -938,7 +1051,10 @@ int sph_mgpu_get_stats(sph_mgpu *m, SphMgpuStats *out, int reset) {
         SphKernelTimes kt{};
         SPHM(m, sl, sph_get_kernel_times(sl.h, &kt, reset));
         m->stats.owned[k] = sl.n_own;
-        m->stats.kernel_s[k] = kt.hash + kt.sort + kt.gather + kt.density + kt.force;
+        m->stats.grid_s[k] = kt.hash + kt.sort + kt.gather;
+        m->stats.density_s[k] = kt.density;
+        m->stats.force_s[k] = kt.force;
+        m->stats.kernel_s[k] = m->stats.grid_s[k] + kt.density + kt.force;
     }
     *out = m->stats;
     if (reset) {

@@ -359,6 +359,8 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.i_begin = 0;
     A.i_end = h->n;
     A.i_origin = 0;
+    A.i_begin2 = A.i_end2 = 0;
+    A.nblk1 = 0;
     A.patchHalo = 0;
     A.n_all = h->n;
     A.tileChunk = tile_chunk(h, h->n, h->zLayers);
@@ -398,14 +400,14 @@ int resolve_pair(sph_handle *h, PairEvent &pe) {
 }
 
 // begin a timed section whose GPU time is added to *target when resolved
-int pair_begin(sph_handle *h, double *target, PairEvent **out) {
+int pair_begin(sph_handle *h, double *target, PairEvent **out, hipStream_t stream = nullptr) {
     PairEvent &pe = h->pairs[h->pairHead];
     int rc = resolve_pair(h, pe);
     if (rc) return rc;
     h->pairHead = (h->pairHead + 1) % kPairRing;
     pe.target = target;
     pe.used = true;
-    HIPCHK(h, hipEventRecord(pe.a, h->compute));
+    HIPCHK(h, hipEventRecord(pe.a, stream ? stream : h->compute));
     *out = &pe;
     return SPH_OK;
 }
@@ -610,7 +612,7 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     return SPH_OK;
 }
 
-int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
+int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all, void *hip_stream) {
     if (!h) return SPH_EINVAL;
     int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
     if (rc) return rc;
@@ -620,30 +622,46 @@ int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_al
     A.i_begin = i_begin;
     A.i_end = i_end;
     A.n_all = n_all;
-    sph_launch_patch_halo(A, h->compute);
+    sph_launch_patch_halo(A, hip_stream ? (hipStream_t)hip_stream : h->compute);
     HIPCHK(h, hipGetLastError());
     return SPH_OK;
 }
 
-int sph_slab_force_range(sph_handle *h, int buf, int i_origin, int a, int b, int n_all, int last) {
+int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, int a1, int b1,
+                          int n_all, int last, void *hip_stream) {
     if (!h) return SPH_EINVAL;
-    int rc = slab_range_ok(h, buf, a, b, n_all);
+    int rc = slab_range_ok(h, buf, a0, b0 > a0 ? b0 : a0, n_all);
+    if (!rc) rc = slab_range_ok(h, buf, a1, b1 > a1 ? b1 : a1, n_all);
     if (rc) return rc;
-    if (i_origin < 0 || i_origin > a) return fail(h, SPH_EINVAL, "bad wave origin");
+    if (i_origin < 0 || (b0 > a0 && i_origin > a0) || (b1 > a1 && (i_origin > a1 || a1 < b0)))
+        return fail(h, SPH_EINVAL, "bad wave origin / ranges must ascend");
     if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
-    if (b > a) {
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->compute;
+    if (b0 > a0 || b1 > a1) {
         SweepArgs A = make_sweep_args(h);
-        A.i_begin = a;
-        A.i_end = b;
         A.i_origin = i_origin;
         A.patchHalo = 0;
         A.n_all = n_all;
-        A.tileChunk = tile_chunk(h, b - a, h->zLayers);
         A.force_out = nullptr;
         PairEvent *pe = nullptr;
-        if ((rc = pair_begin(h, &h->kt.force, &pe))) return rc;
-        sph_launch_force(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
-        HIPCHK(h, hipEventRecord(pe->b, h->compute));
+        if ((rc = pair_begin(h, &h->kt.force, &pe, s))) return rc;
+        if (h->opt.sweep == SPH_SWEEP_LIST) { // both ranges in one launch: one grid, one tail
+            A.i_begin = a0;
+            A.i_end = b0 > a0 ? b0 : a0;
+            A.i_begin2 = a1;
+            A.i_end2 = b1 > a1 ? b1 : a1;
+            A.tileChunk = tile_chunk(h, (b0 > a0 ? b0 - a0 : 0) + (b1 > a1 ? b1 - a1 : 0), h->zLayers);
+            sph_launch_force(h->P, A, h->opt.math_mode, h->opt.sweep, s);
+        } else {
+            for (int k = 0; k < 2; ++k) {
+                A.i_begin = k ? a1 : a0;
+                A.i_end = k ? b1 : b0;
+                if (A.i_end <= A.i_begin) continue;
+                A.tileChunk = tile_chunk(h, A.i_end - A.i_begin, h->zLayers);
+                sph_launch_force(h->P, A, h->opt.math_mode, h->opt.sweep, s);
+            }
+        }
+        HIPCHK(h, hipEventRecord(pe->b, s));
         HIPCHK(h, hipGetLastError());
     }
     if (last) h->kt.steps += 1;

@@ -103,6 +103,9 @@ struct SweepArgs {
     int i_begin, i_end;       // owned range (whole array for one domain)
     int i_origin;             // list sweep: particle 0 of wave 0 of the hit stream (the density
                               // sweep's i_begin); a force launch may cover a sub-range of it
+    int i_begin2, i_end2;     // list sweep force launch: an optional SECOND row range in the same
+                              // launch (a slab's two boundary layers: one grid, one tail); empty = {0,0}
+    int nblk1;                // ... blocks of the launch that belong to the first range
     int n_all;
     int patchHalo;            // list sweep force launch: copy the halo rows' vel4 into pv8 first
     int tileChunk;            // xcd_tile(): 256-particle tiles per chunk (1/8 z-layer), 0 = eighths

@@ -447,12 +447,14 @@ void sph_launch_density(const DevParams &P, const SweepArgs &A, int mathMode, in
 
 void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode, int sweep,
                       hipStream_t s) {
+    if (sweep == 0) { // (may carry a second row range: sizes its own launch)
+        sph_launch_force_list(P, A, mathMode, s);
+        return;
+    }
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
     int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-    if (sweep == 0)
-        sph_launch_force_list(P, A, mathMode, s);
-    else if (sweep == 3)
+    if (sweep == 3)
         sph_launch_force_linked(P, A, s);
     else if (sweep == 1)
         k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)

@@ -412,11 +412,15 @@ void k_force_list(DevParams P, SweepArgs A) {
     // wave w of the hit stream owns particles [i_origin + 64 w, +64); this launch covers
     // the waves that intersect [i_begin, i_end) (a sub-range when the slab driver runs the
     // interior while the halo densities are still in flight)
-    const int tileIdx = ((A.i_begin - A.i_origin) >> 6) / (SL_K2_THREADS / SPH_WAVE) +
-                        xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K2_THREADS));
+    const bool second = (int)blockIdx.x >= A.nblk1; // wave-uniform: blocks past nblk1 serve range 2
+    const int rb = second ? A.i_begin2 : A.i_begin, re = second ? A.i_end2 : A.i_end;
+    const int tileIdx = ((rb - A.i_origin) >> 6) / (SL_K2_THREADS / SPH_WAVE) +
+                        xcd_tile(second ? (int)blockIdx.x - A.nblk1 : (int)blockIdx.x,
+                                 second ? (int)gridDim.x - A.nblk1 : A.nblk1,
+                                 A.tileChunk * (256 / SL_K2_THREADS));
     const int i = A.i_origin + tileIdx * blockDim.x + threadIdx.x;
-    const bool valid = i >= A.i_begin && i < A.i_end;
-    const int iSafe = valid ? i : A.i_begin;
+    const bool valid = i >= rb && i < re;
+    const int iSafe = valid ? i : rb;
     float4 pi = A.pv8[2 * (size_t)iSafe];
     const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
     const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
@@ -593,8 +597,10 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
 // waves with nothing to do leave after one load.
 template <bool FAST>
 __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, SweepArgs A) {
+    // one launch over the hull of the (up to two) row ranges of the force launch
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = i < A.i_end && A.maskOff[2 * (size_t)((i - A.i_origin) >> 6)] == SL_NONE;
+    const bool inRange = i < A.i_end || (i >= A.i_begin2 && i < A.i_end2);
+    const bool mine = inRange && A.maskOff[2 * (size_t)((i - A.i_origin) >> 6)] == SL_NONE;
     if (!__ballot(mine)) return;
     const int iSafe = mine ? i : A.i_begin;
     float4 pi = A.pv8[2 * (size_t)iSafe];
@@ -634,19 +640,31 @@ void sph_launch_patch_halo(const SweepArgs &A, hipStream_t s) {
 }
 
 void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
-    int cnt = A.i_end - A.i_begin;
-    if (cnt <= 0) return;
-    int blocks = (cnt + SW_THREADS - 1) / SW_THREADS;
-    if (A.patchHalo) sph_launch_patch_halo(A, s);
-    // waves of the stream (numbered from i_origin) that hold particles of [i_begin, i_end)
-    const int w0 = (A.i_begin - A.i_origin) >> 6, w1 = (A.i_end - A.i_origin + 63) >> 6;
+    SweepArgs B = A;
+    if (B.i_end2 <= B.i_begin2) B.i_begin2 = B.i_end2 = 0;
+    if (B.i_end <= B.i_begin) { // only the second range holds rows
+        B.i_begin = B.i_begin2;
+        B.i_end = B.i_end2;
+        B.i_begin2 = B.i_end2 = 0;
+    }
+    if (B.i_end <= B.i_begin) return;
+    if (B.patchHalo) sph_launch_patch_halo(B, s);
+    // waves of the stream (numbered from i_origin) that hold rows of a range
     const int wpb = SL_K2_THREADS / SPH_WAVE;
-    const int fblocks = (w1 + wpb - 1) / wpb - w0 / wpb;
+    auto blocks_of = [&](int a, int b) {
+        if (b <= a) return 0;
+        const int w0 = (a - B.i_origin) >> 6, w1 = (b - B.i_origin + 63) >> 6;
+        return (w1 + wpb - 1) / wpb - w0 / wpb;
+    };
+    B.nblk1 = blocks_of(B.i_begin, B.i_end);
+    const int fblocks = B.nblk1 + blocks_of(B.i_begin2, B.i_end2);
+    const int hullEnd = B.i_end2 > B.i_begin2 ? B.i_end2 : B.i_end;
+    const int blocks = (hullEnd - B.i_begin + SW_THREADS - 1) / SW_THREADS;
     if (mathMode == 1) {
-        k_force_list<true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, A);
-        k_force_fallback<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_list<true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        k_force_fallback<true><<<blocks, SW_THREADS, 0, s>>>(P, B);
     } else {
-        k_force_list<false><<<fblocks, SL_K2_THREADS, 0, s>>>(P, A);
-        k_force_fallback<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_list<false><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        k_force_fallback<false><<<blocks, SW_THREADS, 0, s>>>(P, B);
     }
 }

@@ -19,12 +19,13 @@ from ._lib import SphError, SphSettings, SphTimes, load_library
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_LOCAL = 8
-TRANSPORTS = {"loopback": 0, "rccl": 1, "rccl_self": 2}
+TRANSPORTS = {"loopback": 0, "rccl": 1, "rccl_self": 2, "mailbox": 3}
 
 # every symbol include/sph_mgpu.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "sph_mgpu_unique_id", "sph_mgpu_create", "sph_mgpu_destroy", "sph_mgpu_setup",
-    "sph_mgpu_upload_state", "sph_mgpu_step", "sph_mgpu_positions_host", "sph_mgpu_download_state",
+    "sph_mgpu_upload_state", "sph_mgpu_step", "sph_mgpu_step_phase", "sph_mgpu_positions_host",
+    "sph_mgpu_download_state",
     "sph_mgpu_sync", "sph_mgpu_get_stats", "sph_mgpu_last_error",
 ]
 
@@ -39,7 +40,8 @@ class SphMgpuOptions(C.Structure):
 class SphMgpuStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("host_syncs", C.c_int64), ("overflow_rounds", C.c_int64),
                 ("recuts", C.c_int64), ("local_slabs", C.c_int32), ("owned", C.c_int32 * MAX_LOCAL),
-                ("kernel_s", C.c_double * MAX_LOCAL)]
+                ("kernel_s", C.c_double * MAX_LOCAL), ("grid_s", C.c_double * MAX_LOCAL),
+                ("density_s", C.c_double * MAX_LOCAL), ("force_s", C.c_double * MAX_LOCAL)]
 
 
 def library_path():
@@ -69,6 +71,7 @@ def load_mgpu_library():
     L.sph_mgpu_setup.argtypes = [hp]
     L.sph_mgpu_upload_state.argtypes = [hp, fp, fp, C.c_int]
     L.sph_mgpu_step.argtypes = [hp, C.POINTER(SphTimes)]
+    L.sph_mgpu_step_phase.argtypes = [hp, C.c_int, C.POINTER(SphTimes)]
     L.sph_mgpu_positions_host.argtypes = [hp]
     L.sph_mgpu_positions_host.restype = fp
     L.sph_mgpu_download_state.argtypes = [hp, fp, fp, fp, C.POINTER(C.c_int)]
@@ -149,6 +152,10 @@ class MultiGpuSimulator:
 
     def simulate(self):
         self._check(self._L.sph_mgpu_step(self._h, None), "sph_mgpu_step")
+
+    def step_phase(self, phase, times=None):
+        self._check(self._L.sph_mgpu_step_phase(self._h, int(phase), C.byref(times) if times is not None else None),
+                    "sph_mgpu_step_phase")
 
     def simulateAndTime(self, times):
         self._check(self._L.sph_mgpu_step(self._h, C.byref(times)), "sph_mgpu_step")

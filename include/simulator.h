@@ -63,10 +63,12 @@ struct Particle {
 };
 
 struct sph_handle;
+struct sph_mgpu;
 
 class Simulator {
   private:
-    struct sph_handle *impl;
+    struct sph_handle *impl; // one GPU (include/sph_c_api.h)
+    struct sph_mgpu *multi;  // SPH_GPUS=N: z-slabs over N GPUs (include/sph_mgpu.h)
 
   public:
     const Settings *settings;

@@ -220,8 +220,8 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all);
  * Everything is queued on the handle's stream (sph_get_stream: a hipStream_t) and
  * nothing blocks: the bounds are only written to DEVICE memory (bounds_dev_out:
  * nthr+1 int32 = the bounds, then `count`), from where the driver sends them to the
- * neighbours / copies them to pinned memory.  sph_slab_force_range runs the force +
- * integration sweep for rows [a, b) of the owned range whose hit stream was recorded
+ * neighbours / copies them to pinned memory.  sph_slab_force_ranges runs the force +
+ * integration sweep for row ranges of the owned range whose hit stream was recorded
  * by sph_slab_density(buf, i_origin, ...): the interior rows can run while the halo
  * densities are still in flight, the two boundary layers after sph_slab_patch_halo. */
 void *sph_get_stream(sph_handle *h);
@@ -229,9 +229,11 @@ int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int cou
                              const uint32_t *thresholds, int nthr, void *bounds_dev_out);
 int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
                         const uint32_t *thresholds, int nthr, void *bounds_dev_out);
-int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all);
-int sph_slab_force_range(sph_handle *h, int buf, int i_origin, int a, int b, int n_all,
-                         int last_range_of_the_step);
+int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all, void *hip_stream);
+/* rows [a0, b0) and [a1, b1) (either may be empty; a1 >= b0) of the owned range, in ONE
+ * launch; hip_stream NULL = the handle's stream. */
+int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, int a1, int b1,
+                          int n_all, int last_launch_of_the_step, void *hip_stream);
 
 const char *sph_build_info(void);
 

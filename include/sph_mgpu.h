@@ -44,7 +44,12 @@ extern "C" {
 enum {
     SPH_TRANSPORT_LOOPBACK = 0,  /* device-to-device copies; every slab on devices[0] */
     SPH_TRANSPORT_RCCL = 1,      /* ncclSend/ncclRecv between the slabs' GPUs */
-    SPH_TRANSPORT_RCCL_SELF = 2  /* one-rank communicator, every message sent to itself */
+    SPH_TRANSPORT_RCCL_SELF = 2, /* one-rank communicator, every message sent to itself */
+    SPH_TRANSPORT_MAILBOX = 3    /* TEST HOOK for the one-process-per-GPU code path on a one-GPU box:
+                                    `world` driver objects of one slab each live in ONE process on one
+                                    device and stand for the ranks; a message is a note in a process-wide
+                                    table.  Every object must be stepped phase by phase
+                                    (sph_mgpu_step_phase 1..4 on all ranks before the next phase). */
 };
 
 typedef struct SphMgpuOptions {
@@ -69,7 +74,10 @@ typedef struct SphMgpuStats {
     int64_t recuts;
     int32_t local_slabs;
     int32_t owned[SPH_MGPU_MAX_LOCAL];     /* particles per local slab now */
-    double kernel_s[SPH_MGPU_MAX_LOCAL];   /* GPU time of the slab's kernels (sort+density+force) */
+    double kernel_s[SPH_MGPU_MAX_LOCAL];   /* GPU time of the slab's kernels: the sum of the next three */
+    double grid_s[SPH_MGPU_MAX_LOCAL];     /*   partition + combined sort + gather / cell table */
+    double density_s[SPH_MGPU_MAX_LOCAL];  /*   kernelUpdatePressureAndDensity (computeDensity) */
+    double force_s[SPH_MGPU_MAX_LOCAL];    /*   force + integrate, all ranges */
 } SphMgpuStats;
 
 typedef struct sph_mgpu sph_mgpu;
@@ -88,6 +96,9 @@ int sph_mgpu_setup(sph_mgpu *m);
 int sph_mgpu_upload_state(sph_mgpu *m, const float *pos_xyz, const float *vel_xyz, int n);
 /* Simulator::simulate / simulateAndTime (simulator.cu:462-546) over all local slabs. */
 int sph_mgpu_step(sph_mgpu *m, SphTimes *times);
+/* The four phases of a step on their own (1: partition + exchange A, 2: headers + host sync,
+ * 3: assemble/sort/density + exchange B, 4: force + read-back), in this order. */
+int sph_mgpu_step_phase(sph_mgpu *m, int phase, SphTimes *times);
 /* Simulator::getPosition: numParticles x (x,y,z), particle-id order; rows of particles
  * owned by other processes keep their last known value (one process per GPU). */
 const float *sph_mgpu_positions_host(sph_mgpu *m);

@@ -138,3 +138,17 @@ def test_cli_free_mode_with_click_matches_the_oracle():
     want = hashlib.sha256(np.ascontiguousarray(ref.download()["pos"]).tobytes()).hexdigest()
     ref.close()
     assert _sha_of(r.stdout) == want
+
+
+@pytest.mark.gpu
+def test_cli_multi_gpu_mode_equals_single_gpu():
+    """SPH_GPUS=N routes the same Simulator class through the in-process multi-GPU
+    driver (include/sph_mgpu.h); with the loopback transport the N slabs share the one
+    GPU of the test box.  Same sha256 as the single-GPU run, table still printed."""
+    args = ("-n", "262144", "-i", "random", "-m", "time")
+    one = run(*args, env={"SPH_PRINT_SHA256": "1"})
+    assert one.returncode == 0, one.stderr
+    four = run(*args, env={"SPH_PRINT_SHA256": "1", "SPH_GPUS": "4", "SPH_TRANSPORT": "loopback"})
+    assert four.returncode == 0, four.stderr
+    assert "Grid construction" in four.stdout
+    assert _sha_of(four.stdout) == _sha_of(one.stdout)

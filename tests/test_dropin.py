@@ -95,7 +95,8 @@ def test_reference_main_builds_and_links_against_library():
     """Build the reference's main.cpp (compiled from a temp copy of nothing: the
     file is #included from where it lies, with the current directory set so that
     its quoted includes find OUR headers) and link it with our simulator +
-    headless stub + libsph_hip.so.  Link only -- running needs a GPU."""
+    headless stub + libsph_hip.so (+ libsph_mgpu.so, the SPH_GPUS=N path of the same
+    Simulator class).  Link only -- running needs a GPU."""
     lib = os.path.join(ROOT, "cudafluidsimulator_amd", "libsph_hip.so")
     csrc = os.path.join(ROOT, "cudafluidsimulator_amd", "csrc")
     with tempfile.TemporaryDirectory() as d:
@@ -112,7 +113,8 @@ def test_reference_main_builds_and_links_against_library():
         subprocess.run(cmd, input=text, text=True, check=True)
         exe = os.path.join(d, "sph_refmain")
         subprocess.check_call(["g++", "-o", exe, obj, os.path.join(csrc, "simulator.o"),
-                               os.path.join(csrc, "headless.o"), lib,
+                               os.path.join(csrc, "headless.o"),
+                               os.path.join(os.path.dirname(lib), "libsph_mgpu.so"), lib,
                                "-Wl,-rpath," + os.path.dirname(lib)])
         out = subprocess.run([exe, "-i", "bogus"], capture_output=True, text=True)
         assert out.returncode == 1 and "Invalid argument for option -i" in out.stdout

@@ -168,3 +168,41 @@ def test_sinking_fluid_recut_moves_the_cuts():
     owned = list(st.owned[:world])
     assert max(owned) - min(owned) < 0.25 * n / world, owned
     mg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,face", [(2, 0), (4, 0), (3, 250)])
+def test_one_object_per_rank_code_path(world, face):
+    """The one-process-per-GPU code path (every driver object sees ONE slab; what its
+    neighbours hold it only knows from their message headers) on a one-GPU box: `world`
+    objects in this process stand for the ranks, messages go through the mailbox
+    transport, every object is stepped phase by phase.  Bit-equal to the single domain."""
+    n, steps = 60000, 6
+    pos, vel = moving_state(n, 17, vz=14.0)
+    settings = sph.default_settings(n, False)
+    want, _ = single_domain(settings, pos, vel, steps)
+    ranks = [M.MultiGpuSimulator(settings, world=world, rank=r, devices=[0], transport="mailbox",
+                                 face_capacity=face) for r in range(world)]
+    for mg in ranks:
+        mg.upload_state(pos, vel)
+    for _ in range(steps):
+        for phase in (1, 2, 3, 4):
+            for mg in ranks:
+                mg.step_phase(phase)
+    pos_got = np.full((n, 3), np.nan, np.float32)
+    rho_got = np.full(n, np.nan, np.float32)
+    total = 0
+    for mg in ranks:
+        d = mg.download_state()
+        own = ~np.isnan(d["rho"])
+        assert own.sum() == d["written"]
+        assert np.isnan(rho_got[own]).all(), "a particle is owned by two ranks"
+        pos_got[own] = d["pos"][own]
+        rho_got[own] = d["rho"][own]
+        total += d["written"]
+        assert mg.stats().host_syncs == steps
+    assert total == n
+    assert_bit_equal(pos_got, want["pos"], "pos")
+    assert_bit_equal(rho_got, want["rho"], "rho")
+    for mg in ranks:
+        mg.close()
