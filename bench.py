@@ -191,8 +191,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_mgpu = bool(os.environ.get("SPH_BENCH_FORCE_MGPU"))  # tests: the N>1 code path with one rank
+    if world > 1 or force_mgpu:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("SPH_BENCH_SINGLE_DEVICE"):
             # rehearsal of the multi-rank path on a one-GPU box: every rank uses
             # cuda:0 and messages bounce through the host over gloo (never a result)
@@ -218,8 +222,8 @@ def main():
     if world > 1 and os.environ.get("SPH_BENCH_SINGLE_DEVICE"):
         from cudafluidsimulator_amd.slab import run_slab_bench   # gloo rehearsal of the Python driver
         result = run_slab_bench(args, dist, rank, world, local_rank)
-    elif world > 1 or args.loopback_slabs > 1:
-        result = run_mgpu_bench(args, dist if world > 1 else None, rank, world, local_rank)
+    elif world > 1 or args.loopback_slabs > 1 or force_mgpu:
+        result = run_mgpu_bench(args, dist if (world > 1 or force_mgpu) else None, rank, world, local_rank)
     else:
         s = sph.default_settings(n, random_init)
         # the timed run carries no counting code at all (SPH_FLAG_COUNT_PAIRS adds atomics
@@ -297,7 +301,7 @@ def main():
             result["fast_elapsed"] = time.perf_counter() - f0
             fsim.close()
 
-    if world > 1:
+    if world > 1 or force_mgpu:
         t = torch.tensor([result["elapsed"]], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         result["elapsed"] = float(t.item())
@@ -419,7 +423,7 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if world > 1:
+    if world > 1 or force_mgpu:
         dist.barrier()
         dist.destroy_process_group()
 
