@@ -41,8 +41,12 @@ def parse():
     ap.add_argument("--math", choices=["strict", "fast"], default="strict",
                     help="strict: bit-identical to the oracle (default); fast: FMA + approximate "
                          "rcp/rsq, tolerance-checked")
-    ap.add_argument("--mode", choices=["time", "free"], default="time",
-                    help="time: simulateAndTime loop (-m time); free: simulate() loop")
+    ap.add_argument("--mode", choices=["time", "free", "display"], default="time",
+                    help="time: simulateAndTime loop (-m time); free: simulate() loop; display: "
+                         "simulate() + getPosition() every frame like display.cpp:36-37")
+    ap.add_argument("--readback", choices=["copy", "mapped"], default="copy",
+                    help="copy: overlapped device->host copy per step (default); mapped: the force sweep "
+                         "writes getPosition()'s buffer in host-mapped memory (zero-copy)")
     ap.add_argument("--no-linked-leg", action="store_true",
                     help="skip the secondary run of the reference's linked-list neighbour structure")
     ap.add_argument("--no-fast-leg", action="store_true",
@@ -228,23 +232,28 @@ def main():
         s = sph.default_settings(n, random_init)
         # the timed run carries no counting code at all (SPH_FLAG_COUNT_PAIRS adds atomics
         # to the density sweep); pair tests and hits come from an untimed replay below
-        sim = sph.Simulator(s, sweep=args.sweep, flags=0, device=local_rank, math=args.math)
+        rb_flag = _lib.SPH_FLAG_MAPPED_POSITIONS if args.readback == "mapped" else 0
+
+        def one_step(sm, tm):
+            if args.mode == "time":
+                sm.simulateAndTime(tm)
+            else:
+                sm.simulate()
+                if args.mode == "display":
+                    sm.getPosition()  # blocks until this frame's positions are on the host
+        sim = sph.Simulator(s, sweep=args.sweep, flags=rb_flag, device=local_rank, math=args.math)
         sim.setup()
         times = sph.Times()
         for _ in range(W):
-            sim.simulateAndTime(times) if args.mode == "time" else sim.simulate()
+            one_step(sim, times)
         sim.sync()
         sim.setup()  # back to the initial condition: timed steps are steps 1..K
         sim.kernel_times(reset=True)
         times = sph.Times()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if args.mode == "time":
-            for _ in range(K):
-                sim.simulateAndTime(times)
-        else:
-            for _ in range(K):
-                sim.simulate()
+        for _ in range(K):
+            one_step(sim, times)
         sim.sync()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0

@@ -10,6 +10,7 @@ SPH_SWEEP_LIST, SPH_SWEEP_DIRECT, SPH_SWEEP_LDS = 0, 1, 2
 SWEEPS = {"list": 0, "direct": 1, "lds": 2, "linked": 3}
 SPH_FLAG_COUNT_PAIRS, SPH_FLAG_STORE_FORCE, SPH_FLAG_NO_READBACK = 1, 2, 4
 SPH_FLAG_EXTERNAL_STATE = 8
+SPH_FLAG_MAPPED_POSITIONS = 16
 
 # every symbol include/sph_c_api.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [

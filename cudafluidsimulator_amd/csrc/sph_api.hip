@@ -62,6 +62,7 @@ struct sph_handle {
     int2 *cellRange = nullptr;
     float *devPos[2] = {nullptr, nullptr};
     float *hostPos = nullptr; // pinned, n*3
+    bool mappedPos = false;   // SPH_FLAG_MAPPED_POSITIONS: devPos[] alias hostPos (host-mapped)
     hipEvent_t computeDone[2] = {nullptr, nullptr}, copyDone[2] = {nullptr, nullptr};
     bool copyPending[2] = {false, false};
     long long stepIndex = 0;
@@ -202,7 +203,8 @@ int alloc_device(sph_handle *h) {
         }
         HIPCHK(h, hipMalloc(&h->ws.keys[b], cap * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->ws.vals[b], cap * sizeof(uint32_t)));
-        HIPCHK(h, hipMalloc(&h->devPos[b], posCap * 3 * sizeof(float)));
+        if (!(h->opt.flags & SPH_FLAG_MAPPED_POSITIONS))
+            HIPCHK(h, hipMalloc(&h->devPos[b], posCap * 3 * sizeof(float)));
         HIPCHK(h, hipMemset(h->ws.keys[b], 0, cap * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->ws.vals[b], 0, cap * sizeof(uint32_t)));
         HIPCHK(h, hipEventCreateWithFlags(&h->computeDone[b], hipEventDisableTiming));
@@ -216,7 +218,16 @@ int alloc_device(sph_handle *h) {
     HIPCHK(h, hipMalloc(&h->ws.digitTotal, 1024 * sizeof(uint32_t)));
     HIPCHK(h, hipMalloc(&h->cellRange, (size_t)h->P.numCells * sizeof(int2)));
     HIPCHK(h, hipMemset(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2)));
-    HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
+    if (h->opt.flags & SPH_FLAG_MAPPED_POSITIONS) {
+        // zero-copy: the force sweep's id-ordered scatter goes over PCIe into this buffer
+        HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocMapped));
+        void *dp = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, h->hostPos, 0));
+        h->devPos[0] = h->devPos[1] = static_cast<float *>(dp);
+        h->mappedPos = true;
+    } else {
+        HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
+    }
     memset(h->hostPos, 0, posCap * 3 * sizeof(float));
     if (h->opt.sweep == SPH_SWEEP_LIST) {
         // Hit-stream pool (sweeps_list.hip): a wave reserves Q quads (16 B = two (first
@@ -781,7 +792,7 @@ void sph_destroy(sph_handle *h) {
         if (h->vel4[b] && !h->external) (void)hipFree(h->vel4[b]);
         if (h->ws.keys[b]) (void)hipFree(h->ws.keys[b]);
         if (h->ws.vals[b]) (void)hipFree(h->ws.vals[b]);
-        if (h->devPos[b]) (void)hipFree(h->devPos[b]);
+        if (h->devPos[b] && !h->mappedPos) (void)hipFree(h->devPos[b]);
         if (h->computeDone[b]) (void)hipEventDestroy(h->computeDone[b]);
         if (h->copyDone[b]) (void)hipEventDestroy(h->copyDone[b]);
     }
@@ -911,6 +922,11 @@ int sph_phase_readback(sph_handle *h) {
         return SPH_OK;
     }
     const int slot = (int)(h->stepIndex & 1);
+    if (h->mappedPos) { // the force sweep already wrote the host buffer
+        h->stepIndex++;
+        h->phase = 0;
+        return SPH_OK;
+    }
     HIPCHK(h, hipEventRecord(h->computeDone[slot], h->compute));
     HIPCHK(h, hipStreamWaitEvent(h->copy, h->computeDone[slot], 0));
     if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->c[0], h->copy));

@@ -75,9 +75,14 @@ enum {
     SPH_FLAG_COUNT_PAIRS = 1, /* accumulate the candidate pair-test count per step */
     SPH_FLAG_STORE_FORCE = 2, /* keep per-particle force of the last step (tests)  */
     SPH_FLAG_NO_READBACK = 4, /* skip the per-step D2H of positions (kernel studies) */
-    SPH_FLAG_EXTERNAL_STATE = 8 /* particle streams are caller-owned device buffers
+    SPH_FLAG_EXTERNAL_STATE = 8, /* particle streams are caller-owned device buffers
                                    (sph_bind_buffers); used by the multi-GPU slab
                                    driver so halo send/recv is zero-copy */
+    SPH_FLAG_MAPPED_POSITIONS = 16 /* the id-ordered positions of getPosition() are written by
+                                   the force sweep STRAIGHT into host-mapped pinned memory
+                                   (zero-copy: no per-step device->host copy); SURVEY.md 8f
+                                   rank 3.  Measured slower than the overlapped copy at
+                                   n = 4 M: kept as an option, not the default */
 };
 
 typedef struct SphOptions {
