@@ -43,10 +43,14 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 
 // BITS = 8 or 10 bits per pass: the 20-bit flattened cell key sorts in TWO 10-bit
 // passes (1024 digits, four per thread) instead of three 8-bit ones.
-template <int BITS>
+// HASH: first pass of the grid build -- the key is computed from the particle's position
+// here (getGridCell + flattenGridCoord, simulator.cu:57-82) and stored for the scatter
+// passes, instead of a separate hash kernel writing keys and an iota of values.
+template <int BITS, bool HASH>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
-    int shift, int numBlocks) {
+    int shift, int numBlocks, DevParams P, const float4 *__restrict__ pos4,
+    uint32_t *__restrict__ keysOut) {
     constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
     __shared__ uint32_t hist[DIG];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -59,7 +63,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
     for (int r = 0; r < RS_ITEMS; ++r) {
         long long idx = base + r * SPH_WAVE;
         bool valid = idx < n;
-        uint32_t key = valid ? keys[idx] : 0u;
+        uint32_t key = 0u;
+        if (HASH) {
+            if (valid) {
+                const float4 p = pos4[idx];
+                // IEEE divide like the reference; cells clamped into the table (grid.hip)
+                const int cx = min(max((int)(p.x / P.h), 0), P.D - 1);
+                const int cy = min(max((int)(p.y / P.h), 0), P.D - 1);
+                const int cz = min(max((int)(p.z / P.h), 0), P.D - 1);
+                key = (uint32_t)(cx + cy * P.D + cz * P.D * P.D);
+                keysOut[idx] = key;
+            }
+        } else {
+            key = valid ? keys[idx] : 0u;
+        }
         uint32_t d = (key >> shift) & (DIG - 1);
         unsigned long long m = match_digit<BITS>(d, valid);
         if (valid && lanes_below(m) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(m));
@@ -110,7 +127,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(
     }
 }
 
-template <int BITS>
+// IOTA: the values of this pass are the element indices themselves (first pass of the grid
+// build: nothing wrote an iota to memory)
+template <int BITS, bool IOTA>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
     uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut,
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
         long long idx = base + r * SPH_WAVE;
         bool valid = idx < n;
         key[r] = valid ? keysIn[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? valsIn[idx] : 0u;
+        val[r] = IOTA ? (uint32_t)idx : (valid ? valsIn[idx] : 0u);
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -193,13 +212,39 @@ size_t sph_sort_workspace_blocks(int n) {
 
 template <int BITS>
 static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, int numBlocks,
-                       hipStream_t s) {
-    k_radix_hist<BITS><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
-                                                        numBlocks);
+                       hipStream_t s, const DevParams *P = nullptr, const float4 *pos4 = nullptr) {
+    if (pos4) { // first pass of the grid build: hash fused in, values = iota
+        k_radix_hist<BITS, true><<<numBlocks, RS_THREADS, 0, s>>>(nullptr, ws.blockHist, n, shift, numBlocks,
+                                                                  *P, pos4, ws.keys[cur]);
+        k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
+        k_radix_scatter<BITS, true><<<numBlocks, RS_THREADS, 0, s>>>(
+            ws.keys[cur], nullptr, ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist, ws.digitTotal, n, shift,
+            numBlocks);
+        return;
+    }
+    k_radix_hist<BITS, false><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
+                                                               numBlocks, DevParams{}, nullptr, nullptr);
     k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
-    k_radix_scatter<BITS><<<numBlocks, RS_THREADS, 0, s>>>(
+    k_radix_scatter<BITS, false><<<numBlocks, RS_THREADS, 0, s>>>(
         ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist,
         ws.digitTotal, n, shift, numBlocks);
+}
+
+// The grid build's sort: cell keys computed from pos4 inside the first histogram pass.
+int sph_sort_cells(const SortWorkspace &ws, const DevParams &P, const float4 *pos4, int n, int bits,
+                   hipStream_t s) {
+    if (n <= 0) return 0;
+    const int numBlocks = (n + RS_TILE - 1) / RS_TILE;
+    int digit = 8;
+    if ((bits > 8 && bits <= 10) || (bits > 16 && bits <= 20) || (bits > 24 && bits <= 30)) digit = 10;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += digit) {
+        const bool first = shift == 0;
+        if (digit == 10) radix_pass<10>(ws, cur, n, shift, numBlocks, s, first ? &P : nullptr, first ? pos4 : nullptr);
+        else radix_pass<8>(ws, cur, n, shift, numBlocks, s, first ? &P : nullptr, first ? pos4 : nullptr);
+        cur ^= 1;
+    }
+    return cur;
 }
 
 int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s) {

@@ -40,8 +40,8 @@ struct PairEvent { // one timed section of the slab path
 constexpr int kPairRing = 48;
 
 struct StepEvents {
-    hipEvent_t e[6]; // start, hash, sort, gather, density, force
-    hipEvent_t c[2]; // copy start / end
+    hipEvent_t e[6] = {}; // start, hash, sort, gather, density, force
+    hipEvent_t c[2] = {}; // copy start / end
     bool used = false, hasCopy = false, counted = false;
 };
 
@@ -63,6 +63,16 @@ struct sph_handle {
     float *devPos[2] = {nullptr, nullptr};
     float *hostPos = nullptr; // pinned, n*3
     bool mappedPos = false;   // SPH_FLAG_MAPPED_POSITIONS: devPos[] alias hostPos (host-mapped)
+    // SPH_GRAPH=1: the three phases of a step replayed as hipGraphs (captured once per
+    // read-back slot).  Measured (round 2): SLOWER than plain launches -- n = 262,144:
+    // 0.238 vs 0.214 ms per step, n = 4,194,304: 2.37 vs 2.34 -- a graph replay costs
+    // 10-16 us where the ~15 kernels of a step (>= 5 us each) are not host-bound; off by
+    // default.  Any capture failure falls back to plain launches.
+    hipGraphExec_t stepGraph[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // grid, density, force
+    StepEvents graphEv[2];
+    bool graphEvPending[2] = {false, false};
+    bool useGraph = false, capturing = false;
+    int graphKeyBuf = 0;
     hipEvent_t computeDone[2] = {nullptr, nullptr}, copyDone[2] = {nullptr, nullptr};
     bool copyPending[2] = {false, false};
     long long stepIndex = 0;
@@ -277,6 +287,12 @@ int alloc_device(sph_handle *h) {
         for (auto &e : se.e) HIPCHK(h, hipEventCreate(&e));
         for (auto &e : se.c) HIPCHK(h, hipEventCreate(&e));
     }
+    for (auto &se : h->graphEv) {
+        for (auto &e : se.e) HIPCHK(h, hipEventCreate(&e));
+        for (auto &e : se.c) HIPCHK(h, hipEventCreate(&e));
+    }
+    if (const char *e = getenv("SPH_GRAPH")) h->useGraph = atoi(e) != 0;
+    if (h->external) h->useGraph = false; // slab mode: the driver sizes every launch itself
     HIPCHK(h, hipDeviceSynchronize()); // memsets above ran on the null stream
     return SPH_OK;
 }
@@ -302,6 +318,16 @@ int resolve_events(sph_handle *h, StepEvents &se) {
     se.counted = true;
     se.used = false;
     return SPH_OK;
+}
+
+// the captured launches carry tile_chunk(zLayers): a new state means new graphs
+void drop_step_graphs(sph_handle *h) {
+    for (auto &gs : h->stepGraph)
+        for (auto &g : gs) {
+            if (g) (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
+    h->graphEvPending[0] = h->graphEvPending[1] = false;
 }
 
 int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
@@ -337,6 +363,7 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     }
     HIPCHK(h, hipDeviceSynchronize());
     h->zLayers = zmax >= zmin ? zmax - zmin + 1 : 0;
+    drop_step_graphs(h);
     h->ready = true;
     h->gridValid = false;
     h->phase = 0;
@@ -471,8 +498,7 @@ int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
     PairEvent *pe = nullptr;
     if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
     HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
-    sph_launch_hash(h->P, h->pos4[src_buf] + src_offset, h->ws.keys[0], h->ws.vals[0], count, s);
-    int res = sph_sort_pairs(h->ws, count, key_bits(h), s);
+    int res = sph_sort_cells(h->ws, h->P, h->pos4[src_buf] + src_offset, count, key_bits(h), s);
     sph_launch_gather(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
                       h->ws.vals[res], h->ws.keys[res], h->pos4[src_buf ^ 1],
                       h->vel4[src_buf ^ 1], h->pv8, h->cellRange, count, s);
@@ -807,6 +833,13 @@ void sph_destroy(sph_handle *h) {
         for (auto &e : se.e) if (e) (void)hipEventDestroy(e);
         for (auto &e : se.c) if (e) (void)hipEventDestroy(e);
     }
+    for (auto &se : h->graphEv) {
+        for (auto &e : se.e) if (e) (void)hipEventDestroy(e);
+        for (auto &e : se.c) if (e) (void)hipEventDestroy(e);
+    }
+    for (auto &gs : h->stepGraph)
+        for (auto &g : gs)
+            if (g) (void)hipGraphExecDestroy(g);
     if (h->pv8) (void)hipFree(h->pv8);
     if (h->maskPool) (void)hipFree(h->maskPool);
     if (h->maskOff) (void)hipFree(h->maskOff);
@@ -864,9 +897,8 @@ int sph_phase_grid(sph_handle *h) {
     }
     // kernelResetGrid (simulator.cu:321-326,492-495): 8 MB memset, not 10^6 blocks
     HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
-    sph_launch_hash(h->P, h->pos4[c], h->ws.keys[0], h->ws.vals[0], n, s);
-    if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
-    int res = sph_sort_pairs(h->ws, n, key_bits(h), s);
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s)); // (the hash is part of the first sort pass)
+    int res = sph_sort_cells(h->ws, h->P, h->pos4[c], n, key_bits(h), s);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
     sph_launch_gather(h->pos4[c], h->vel4[c], h->ws.vals[res], h->ws.keys[res],
                       h->pos4[c ^ 1], h->vel4[c ^ 1], h->pv8, h->cellRange, n, s);
@@ -899,7 +931,7 @@ int sph_phase_force(sph_handle *h) {
     const int slot = (int)(h->stepIndex & 1);
     if (!(h->opt.flags & SPH_FLAG_NO_READBACK)) {
         // devPos[slot] was last read by the copy of step k-2
-        if (h->copyPending[slot]) {
+        if (h->copyPending[slot] && !h->capturing) { // (graph mode: waited for before the launch)
             HIPCHK(h, hipStreamWaitEvent(h->compute, h->copyDone[slot], 0));
             h->copyPending[slot] = false;
         }
@@ -944,18 +976,112 @@ int sph_phase_readback(sph_handle *h) {
     return SPH_OK;
 }
 
+namespace {
+
+// Fold the per-kernel events of the graph replay of `slot` (two steps ago) into kt.
+int fold_graph_events(sph_handle *h, int slot) {
+    if (!h->graphEvPending[slot]) return SPH_OK;
+    StepEvents &se = h->graphEv[slot];
+    se.used = true;
+    se.counted = false;
+    h->graphEvPending[slot] = false;
+    return resolve_events(h, se);
+}
+
+// Capture the three phases of one step (read-back slot `slot`) from the compute stream,
+// one graph each: the timing events between them stay ordinary stream events (an event
+// recorded INSIDE a graph cannot be timed: hipEventElapsedTime rejects it).
+int capture_step_graph(sph_handle *h, int slot) {
+    const int phase0 = h->phase, cur0 = h->cur, sorted0 = h->sorted, keybuf0 = h->sortedKeyBuf;
+    const bool grid0 = h->gridValid;
+    h->capturing = true;
+    h->curEv = nullptr;
+    bool ok = true;
+    for (int ph = 0; ph < 3 && ok; ++ph) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(h->compute, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
+        const int rc = ph == 0 ? sph_phase_grid(h) : ph == 1 ? sph_phase_density(h) : sph_phase_force(h);
+        const hipError_t e = hipStreamEndCapture(h->compute, &g);
+        ok = !rc && e == hipSuccess && g;
+        if (ok) ok = hipGraphInstantiate(&h->stepGraph[slot][ph], g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+    }
+    h->capturing = false;
+    h->graphKeyBuf = h->sortedKeyBuf;
+    // the captured calls only recorded work: restore the host-side state they advanced
+    h->phase = phase0;
+    h->cur = cur0;
+    h->sorted = sorted0;
+    h->sortedKeyBuf = keybuf0;
+    h->gridValid = grid0;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (auto &x : h->stepGraph[slot]) {
+            if (x) (void)hipGraphExecDestroy(x);
+            x = nullptr;
+        }
+        return SPH_EHIP;
+    }
+    return SPH_OK;
+}
+
+} // namespace
+
 int sph_step(sph_handle *h, SphTimes *times) {
     if (!h) return SPH_EINVAL;
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
+    if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "a step split into phases is still open");
     int rc;
     // slot of the PREVIOUS step's position copy (if any)
     const int prevSlot = (int)((h->stepIndex + 1) & 1);
     const bool prevCopy = h->stepIndex > 0 && h->copyPending[prevSlot];
-    if ((rc = begin_step_events(h))) return rc;
-    StepEvents *ev = h->curEv;
-    if ((rc = sph_phase_grid(h))) return rc;
-    if ((rc = sph_phase_density(h))) return rc;
-    if ((rc = sph_phase_force(h))) return rc;
+    StepEvents *ev = nullptr;
+    const int slot = (int)(h->stepIndex & 1);
+    bool viaGraph = false;
+    if (h->useGraph && h->opt.sweep != SPH_SWEEP_LINKED && h->n > 0) {
+        if ((rc = fold_graph_events(h, slot))) return rc;
+        if (!h->stepGraph[slot][2] && capture_step_graph(h, slot) != SPH_OK) h->useGraph = false;
+        if (h->stepGraph[slot][2]) {
+            if (!(h->opt.flags & SPH_FLAG_NO_READBACK) && h->copyPending[slot]) {
+                // devPos[slot] was last read by the copy of step k-2
+                HIPCHK(h, hipStreamWaitEvent(h->compute, h->copyDone[slot], 0));
+                h->copyPending[slot] = false;
+            }
+            ev = &h->graphEv[slot];
+            hipStream_t cs = h->compute;
+            // e[0] = e[1] | grid graph | e[2] = e[3] | density graph | e[4] | force graph | e[5]: the
+            // whole grid build is booked as "sort" (its kernels are not timed one by one here)
+            bool ok = hipEventRecord(ev->e[0], cs) == hipSuccess && hipEventRecord(ev->e[1], cs) == hipSuccess &&
+                      hipGraphLaunch(h->stepGraph[slot][0], cs) == hipSuccess &&
+                      hipEventRecord(ev->e[2], cs) == hipSuccess && hipEventRecord(ev->e[3], cs) == hipSuccess &&
+                      hipGraphLaunch(h->stepGraph[slot][1], cs) == hipSuccess &&
+                      hipEventRecord(ev->e[4], cs) == hipSuccess &&
+                      hipGraphLaunch(h->stepGraph[slot][2], cs) == hipSuccess &&
+                      hipEventRecord(ev->e[5], cs) == hipSuccess;
+            if (ok) {
+                viaGraph = true;
+                ev->hasCopy = false;
+                h->graphEvPending[slot] = true;
+                h->curEv = ev; // the read-back below records its copy events here
+                // what the three phase calls would have left behind
+                h->sorted = h->cur ^ 1;
+                h->sortedKeyBuf = h->graphKeyBuf;
+                h->gridValid = true;
+                h->cur = h->sorted ^ 1;
+                h->phase = 3;
+            } else {
+                (void)hipGetLastError();
+                h->useGraph = false;
+            }
+        }
+    }
+    if (!viaGraph) {
+        if ((rc = begin_step_events(h))) return rc;
+        ev = h->curEv;
+        if ((rc = sph_phase_grid(h))) return rc;
+        if ((rc = sph_phase_density(h))) return rc;
+        if ((rc = sph_phase_force(h))) return rc;
+    }
     if ((rc = sph_phase_readback(h))) return rc; // ends the step
     h->curEv = nullptr;
     if (times) {
@@ -1073,6 +1199,7 @@ int sph_load_state(sph_handle *h, const char *path) {
         HIPCHK(h, hipMemcpy(h->vel4[0], v4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     }
     HIPCHK(h, hipDeviceSynchronize());
+    drop_step_graphs(h);
     h->ready = true;
     h->gridValid = false;
     h->phase = 0;
@@ -1162,6 +1289,13 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     if (rc) return rc;
     for (auto &se : h->ring)
         if ((rc = resolve_events(h, se))) return rc;
+    for (int slot = 0; slot < 2; ++slot) {
+        if (!h->graphEvPending[slot]) continue;
+        h->graphEv[slot].used = true;
+        h->graphEv[slot].counted = false;
+        h->graphEvPending[slot] = false;
+        if ((rc = resolve_events(h, h->graphEv[slot]))) return rc;
+    }
     for (auto &pe : h->pairs)
         if ((rc = resolve_pair(h, pe))) return rc;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) {

@@ -56,6 +56,11 @@ size_t sph_sort_workspace_blocks(int n);
 // Stable LSD sort of (keys[0], vals[0]) on `bits` key bits; returns the index
 // (0/1) of the buffer pair that holds the result.
 int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s);
+struct DevParams;
+// Same, for the grid build: the keys are the flattened cell indices of pos4[0..n), computed
+// inside the first histogram pass (no separate hash kernel, no iota of values in memory).
+int sph_sort_cells(const SortWorkspace &ws, const DevParams &P, const float4 *pos4, int n, int bits,
+                   hipStream_t s);
 
 // ---- grid build (grid.hip) ----
 void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
