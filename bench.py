@@ -38,6 +38,8 @@ def parse():
                     help="BASELINE.json configs[2]: -n 4194304 -i random -m time")
     ap.add_argument("--init", choices=["random", "grid"], default="random")
     ap.add_argument("--sweep", choices=["list", "lds", "direct", "linked"], default="list")
+    ap.add_argument("--key", choices=["flattened", "morton"], default="flattened",
+                    help="cell key of the grid build's sort; morton: --sweep direct only (ordering A/B)")
     ap.add_argument("--math", choices=["strict", "fast"], default="strict",
                     help="strict: bit-identical to the oracle (default); fast: FMA + approximate "
                          "rcp/rsq, tolerance-checked")
@@ -241,7 +243,8 @@ def main():
                 sm.simulate()
                 if args.mode == "display":
                     sm.getPosition()  # blocks until this frame's positions are on the host
-        sim = sph.Simulator(s, sweep=args.sweep, flags=rb_flag, device=local_rank, math=args.math)
+        sim = sph.Simulator(s, sweep=args.sweep, flags=rb_flag, device=local_rank, math=args.math,
+                            key_order=args.key)
         sim.setup()
         times = sph.Times()
         for _ in range(W):
@@ -266,7 +269,7 @@ def main():
             # untimed replay of the same K steps with the counters on (the run is
             # deterministic: same trajectory, same pair tests and hits per step)
             csim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank,
-                                 math=args.math)
+                                 math=args.math, key_order=args.key)
             csim.setup()
             for _ in range(K):
                 csim.simulate()
@@ -373,7 +376,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"-n {result['n_total']} -i {args.init} -m {args.mode}, "
-                                   f"{world}xMI355X, flattened-index radix sort + float4 SoA, sweep={args.sweep}, "
+                                   f"{world}xMI355X, {args.key}-index radix sort + float4 SoA, sweep={args.sweep}, "
                                    + ("strict fp32 (bit-identical to the CPU oracle)" if args.math == "strict"
                                       else "FAST fp32 math (FMA, approximate rcp/rsq; 1e-5 tolerance mode)"),
                        "sweep": args.sweep,

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_partition", "sph_slab_copy_segments", "sph_slab_density",
     "sph_slab_force", "sph_initial_positions", "sph_save_state", "sph_load_state",
     "sph_debug_counters", "sph_get_stream", "sph_slab_partition_async", "sph_slab_sort_async",
-    "sph_slab_patch_halo", "sph_slab_force_ranges",
+    "sph_slab_patch_halo", "sph_slab_force_ranges", "sph_num_table_cells",
 ]
 
 
@@ -46,7 +46,7 @@ class SphTimes(C.Structure):
 class SphOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32),
                 ("math_mode", C.c_int32), ("sweep", C.c_int32), ("flags", C.c_int32),
-                ("capacity", C.c_int32)]
+                ("capacity", C.c_int32), ("key_order", C.c_int32)]
 
 
 class SphKernelTimes(C.Structure):
@@ -97,6 +97,7 @@ def load_library():
     L.sph_save_state.argtypes = [hp, C.c_char_p]
     L.sph_load_state.argtypes = [hp, C.c_char_p]
     L.sph_num_particles.argtypes = [hp]
+    L.sph_num_table_cells.argtypes = [hp]
     L.sph_get_kernel_times.argtypes = [hp, C.POINTER(SphKernelTimes), C.c_int]
     L.sph_last_error.argtypes = [hp]
     L.sph_last_error.restype = C.c_char_p

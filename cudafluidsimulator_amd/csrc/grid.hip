@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_hash(DevParams P,
     if (i >= n) return;
     float4 p = pos4[i];
     int3 c = grid_cell(P, p.x, p.y, p.z);
-    keys[i] = (uint32_t)(c.x + c.y * P.D + c.z * P.D * P.D);
+    keys[i] = sph_cell_key(P, c.x, c.y, c.z);
     vals[i] = (uint32_t)i;
 }
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_classify(DevParams P, const float4 *__r
     if (i >= n) return;
     float4 p = pos4[i];
     int3 c = grid_cell(P, p.x, p.y, p.z);
-    const uint32_t key = (uint32_t)(c.x + c.y * P.D + c.z * P.D * P.D);
+    const uint32_t key = sph_cell_key(P, c.x, c.y, c.z);
     uint32_t cls = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) cls += (k < nthr && key >= thr.v[k]) ? 1u : 0u;
@@ -192,7 +192,7 @@ __global__ void k_click(DevParams P, const int2 *__restrict__ cellRange,
         for (int dx = -2; dx < 3; dx++) {
             int sx = cx + dx;
             if (sx < 0 || sx >= P.D) continue;
-            int2 r = cellRange[sx + sy * P.D + cz * P.D * P.D];
+            int2 r = cellRange[sph_cell_key(P, sx, sy, cz)];
             for (int j = r.x; j < r.y; j++) {
                 float4 v = vel4[j];
                 if (dx != 0) v.x += (1.f / dx) * SPH_PUSH_STRENGTH;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
                 const int cx = min(max((int)(p.x / P.h), 0), P.D - 1);
                 const int cy = min(max((int)(p.y / P.h), 0), P.D - 1);
                 const int cz = min(max((int)(p.z / P.h), 0), P.D - 1);
-                key = (uint32_t)(cx + cy * P.D + cz * P.D * P.D);
+                key = sph_cell_key(P, cx, cy, cz);
                 keysOut[idx] = key;
             }
         } else {

@@ -142,7 +142,14 @@ void fill_params(sph_handle *h) {
     P.dt = s.timestep;
     P.cut2 = force_cut2(s.h);
     P.D = (int)s.numCellsPerDim;
-    P.numCells = P.D * P.D * P.D;
+    P.morton = h->opt.key_order == SPH_KEY_MORTON ? 1 : 0;
+    if (P.morton) {
+        int b = 0;
+        while ((1 << b) < P.D) ++b;
+        P.numCells = 1 << (3 * b);
+    } else {
+        P.numCells = P.D * P.D * P.D;
+    }
 }
 
 int key_bits(const sph_handle *h) {
@@ -778,6 +785,15 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
         delete h;
         return fail(nullptr, SPH_EINVAL, "SPH_MATH_FAST does not exist for SPH_SWEEP_DIRECT/LINKED");
     }
+    if (h->opt.key_order != SPH_KEY_FLATTENED && h->opt.key_order != SPH_KEY_MORTON) {
+        delete h;
+        return fail(nullptr, SPH_EINVAL, "unknown key_order");
+    }
+    if (h->opt.key_order == SPH_KEY_MORTON &&
+        (h->opt.sweep != SPH_SWEEP_DIRECT || (h->opt.flags & SPH_FLAG_EXTERNAL_STATE))) {
+        delete h;
+        return fail(nullptr, SPH_EINVAL, "SPH_KEY_MORTON is served by SPH_SWEEP_DIRECT, single domain, only");
+    }
     if (h->opt.sweep == SPH_SWEEP_LINKED && (h->opt.flags & SPH_FLAG_EXTERNAL_STATE)) {
         delete h;
         return fail(nullptr, SPH_EINVAL, "SPH_SWEEP_LINKED is single-domain only");
@@ -1217,6 +1233,7 @@ int sph_sync(sph_handle *h) {
 }
 
 int sph_num_particles(const sph_handle *h) { return h ? h->n : SPH_EINVAL; }
+int sph_num_table_cells(const sph_handle *h) { return h ? h->P.numCells : SPH_EINVAL; }
 
 int sph_download_state(sph_handle *h, float *pos, float *vel, float *rho, float *prs) {
     if (!h) return SPH_EINVAL;

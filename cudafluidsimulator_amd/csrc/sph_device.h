@@ -34,8 +34,26 @@ struct DevParams {
     float dt;      // timestep
     float cut2;    // largest dist2 for which ANY force term can be non-zero
     int D;         // cells per dimension (numCellsPerDim as int)
-    int numCells;  // D^3
+    int numCells;  // entries of the cell table: D^3 (flattened keys) or 8^ceil(log2 D) (Morton)
+    int morton;    // key function: 0 = flattened cell index (simulator.cu:78-82), 1 = Morton
 };
+
+// The neighbour grid's key function.  Flattened = the reference's x + y D + z D^2; Morton =
+// bits of x, y, z interleaved (x lowest), the ordering the reference's README.md:5 names
+// for its `z_index_sort` branch (not in the checkout).  SPH_KEY_MORTON exists for the A/B
+// of the two orderings and is served by the direct sweep only.
+__device__ __forceinline__ uint32_t sph_spread3(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t sph_cell_key(const DevParams &P, int cx, int cy, int cz) {
+    if (P.morton) return sph_spread3((uint32_t)cx) | (sph_spread3((uint32_t)cy) << 1) | (sph_spread3((uint32_t)cz) << 2);
+    return (uint32_t)(cx + cy * P.D + cz * P.D * P.D);
+}
 
 // Particle state lives in two float4 streams, both in cell-sorted order:
 //   pos4[i] = (x, y, z, bits(original particle id))

@@ -38,14 +38,28 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_direct(DevParams P,
     bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
-    int js[9], je[9];
-    load_runs(P, A.cellRange, c, valid, js, je);
     float rho = 0.f;
     uint32_t pairs = 0;
+    if (P.morton) {
+        // Morton keys: the three x-neighbours are not adjacent in the sorted stream, so the
+        // walk is the reference's 27 cells one by one (simulator.cu:163-176: z outer, x inner)
+        for (int dz = -1; dz < 2; ++dz)
+            for (int dy = -1; dy < 2; ++dy)
+                for (int dx = -1; dx < 2; ++dx) {
+                    const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
+                    if (!valid || x < 0 || x >= P.D || y < 0 || y >= P.D || z < 0 || z >= P.D) continue;
+                    const int2 r = A.cellRange[sph_cell_key(P, x, y, z)];
+                    pairs += (uint32_t)(r.y - r.x);
+                    for (int j = r.x; j < r.y; ++j) density_pair(P, pi.x, pi.y, pi.z, A.pos4[j], rho);
+                }
+    } else {
+        int js[9], je[9];
+        load_runs(P, A.cellRange, c, valid, js, je);
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        pairs += (uint32_t)(je[r] - js[r]);
-        for (int j = js[r]; j < je[r]; ++j) density_pair(P, pi.x, pi.y, pi.z, A.pos4[j], rho);
+        for (int r = 0; r < 9; ++r) {
+            pairs += (uint32_t)(je[r] - js[r]);
+            for (int j = js[r]; j < je[r]; ++j) density_pair(P, pi.x, pi.y, pi.z, A.pos4[j], rho);
+        }
     }
     if (A.pairCounter) {
         uint32_t s = wave_sum_u32(pairs);
@@ -64,14 +78,26 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_direct(DevParams P, SweepA
     float4 vi = A.vel4[i];
     float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
-    int js[9], je[9];
-    load_runs(P, A.cellRange, c, true, js, je);
     ForceAcc F = {0.f, 0.f, 0.f};
+    if (P.morton) {
+        for (int dz = -1; dz < 2; ++dz)
+            for (int dy = -1; dy < 2; ++dy)
+                for (int dx = -1; dx < 2; ++dx) {
+                    const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
+                    if (x < 0 || x >= P.D || y < 0 || y >= P.D || z < 0 || z >= P.D) continue;
+                    const int2 r = A.cellRange[sph_cell_key(P, x, y, z)];
+                    for (int j = r.x; j < r.y; ++j)
+                        force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+                }
+    } else {
+        int js[9], je[9];
+        load_runs(P, A.cellRange, c, true, js, je);
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        for (int j = js[r]; j < je[r]; ++j)
-            force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j],
-                       F);
+        for (int r = 0; r < 9; ++r) {
+            for (int j = js[r]; j < je[r]; ++j)
+                force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j],
+                           F);
+        }
     }
     float vx = vi.x, vy = vi.y, vz = vi.z;
     integrate_particle(P, pi, vx, vy, vz, F, vi.w);

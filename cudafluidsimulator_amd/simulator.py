@@ -45,7 +45,7 @@ def _fp(a):
 
 
 class Simulator:
-    def __init__(self, settings, sweep="list", flags=0, device=-1, capacity=0, math="strict"):
+    def __init__(self, settings, sweep="list", flags=0, device=-1, capacity=0, math="strict", key_order="flattened"):
         self.settings = settings
         self._L = load_library()
         self._h = C.c_void_p()
@@ -56,6 +56,7 @@ class Simulator:
         self._opt.sweep = _lib.SWEEPS[sweep]
         self._opt.flags = flags
         self._opt.capacity = capacity
+        self._opt.key_order = 1 if key_order == "morton" else 0
         rc = self._L.sph_create(C.byref(settings), C.byref(self._opt), C.byref(self._h))
         if rc:
             msg = self._L.sph_last_error(None).decode()
@@ -136,10 +137,9 @@ class Simulator:
 
     def download_grid(self):
         n = self.n
-        d = int(self.settings.numCellsPerDim)
         ids = np.zeros(n, np.uint32)
         keys = np.zeros(n, np.uint32)
-        cells = np.zeros((d * d * d, 2), np.int32)
+        cells = np.zeros((self._L.sph_num_table_cells(self._h), 2), np.int32)
         self._check(self._L.sph_download_grid(
             self._h, ids.ctypes.data_as(C.POINTER(C.c_uint32)),
             keys.ctypes.data_as(C.POINTER(C.c_uint32)),

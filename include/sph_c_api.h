@@ -85,6 +85,14 @@ enum {
                                    n = 4 M: kept as an option, not the default */
 };
 
+enum {
+    SPH_KEY_FLATTENED = 0, /* x + y D + z D^2 (simulator.cu:78-82): the 27-cell walk is nine
+                              contiguous runs of the sorted stream -- what every sweep is built on */
+    SPH_KEY_MORTON = 1     /* bits of x, y, z interleaved (the ordering the reference's README.md:5
+                              names for its z_index_sort branch; BASELINE config 3).  For the A/B of
+                              the two orderings: SPH_SWEEP_DIRECT, strict math, single domain only */
+};
+
 typedef struct SphOptions {
     int32_t struct_size; /* = sizeof(SphOptions) */
     int32_t device;      /* HIP device ordinal; -1 = current */
@@ -93,6 +101,7 @@ typedef struct SphOptions {
     int32_t flags;       /* SPH_FLAG_* */
     int32_t capacity;    /* particle slots to allocate (0 = numParticles); slabs
                             need room for halo + migrants */
+    int32_t key_order;   /* SPH_KEY_* (callers built against the 24-byte struct get FLATTENED) */
 } SphOptions;
 
 /* Per-kernel GPU time, accumulated from HIP events recorded on the handle's
@@ -162,6 +171,8 @@ int sph_load_state(sph_handle *h, const char *path);
 
 int sph_sync(sph_handle *h);
 int sph_num_particles(const sph_handle *h);
+/* entries of the cell table sph_download_grid fills: D^3, or 8^ceil(log2 D) with Morton keys */
+int sph_num_table_cells(const sph_handle *h);
 int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset);
 const char *sph_last_error(const sph_handle *h); /* h may be NULL: create errors */
 /* Diagnostics: [0] = pair tests; [1..] = in-kernel phase stamps, filled only by a

@@ -99,6 +99,9 @@ def lib():
     L.oracle_sim_sorted.restype = C.c_int
     L.oracle_sim_last_pair_tests.argtypes = [C.c_void_p]
     L.oracle_sim_last_pair_tests.restype = C.c_uint64
+    L.oracle_set_key_order.argtypes = [C.c_int]
+    L.oracle_num_keys.argtypes = [C.c_int]
+    L.oracle_num_keys.restype = C.c_int
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_num_threads.argtypes = [C.c_int]
     cap = int(os.environ.get("ORACLE_MAX_THREADS", "16"))
@@ -255,6 +258,15 @@ class OracleSim:
 
     def last_pair_tests(self):
         return int(lib().oracle_sim_last_pair_tests(self._h))
+
+
+def set_key_order(order):
+    """0 = flattened cell index (reference), 1 = Morton.  Set before creating a sim."""
+    lib().oracle_set_key_order(1 if order in (1, "morton") else 0)
+
+
+def num_keys(cells_per_dim=100):
+    return int(lib().oracle_num_keys(int(cells_per_dim)))
 
 
 def num_threads():

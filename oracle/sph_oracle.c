@@ -126,9 +126,37 @@ static inline void get_grid_cell(const OracleSettings *s, const float *p,
     *cz = (int)(p[2] / s->h);
 }
 
+/* Key function of the neighbour grid (the oracle takes it as a parameter
+ * because it changes the tie order of the stable sort).  0 = the reference's flattened
+ * index (simulator.cu:78-82); 1 = Morton / z-order (the reference's README.md:5 names a
+ * `z_index_sort` branch that is not in the checkout: bits of x, y, z interleaved, x lowest).
+ * Process-wide switch: test infrastructure, one simulation at a time. */
+static int g_key_order = 0;
+void oracle_set_key_order(int order) { g_key_order = order ? 1 : 0; }
+int oracle_key_order(void) { return g_key_order; }
+
+static inline uint32_t spread3(uint32_t v) { /* 10 bits -> every third bit */
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+/* number of table entries the key function needs for d cells per axis */
+int oracle_num_keys(int d) {
+    if (!g_key_order) return d * d * d;
+    int b = 0;
+    while ((1 << b) < d) b++;
+    return 1 << (3 * b);
+}
+
 /* simulator.cu:78-82 (evaluated in float there; exact below 2^24) */
 static inline int flatten_grid_coord(const OracleSettings *s, int x, int y,
                                      int z) {
+    if (g_key_order)
+        return (int)(spread3((uint32_t)x) | (spread3((uint32_t)y) << 1) | (spread3((uint32_t)z) << 2));
     return (int)(x + y * s->numCellsPerDim +
                  z * s->numCellsPerDim * s->numCellsPerDim);
 }
@@ -375,7 +403,7 @@ OracleSim *oracle_sim_create(const OracleSettings *s) {
     m->s = *s;
     m->n = s->numParticles;
     int d = (int)s->numCellsPerDim;
-    m->numCells = d * d * d;
+    m->numCells = oracle_num_keys(d);
     size_t n = (size_t)(m->n > 0 ? m->n : 1);
     m->pos = (float *)calloc(3 * n, sizeof(float));
     m->vel = (float *)calloc(3 * n, sizeof(float));

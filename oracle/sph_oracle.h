@@ -119,6 +119,12 @@ uint64_t oracle_sim_last_pair_tests(const OracleSim *sim);
 int oracle_num_threads(void);
 void oracle_set_num_threads(int t); /* OpenMP threads for the sweeps (results do not change) */
 
+/* Key function of the neighbour grid: 0 flattened (reference), 1 Morton.  Set BEFORE
+ * oracle_sim_create; process-wide (test infrastructure). */
+void oracle_set_key_order(int order);
+int oracle_key_order(void);
+int oracle_num_keys(int cells_per_dim);
+
 #ifdef __cplusplus
 }
 #endif

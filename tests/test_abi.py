@@ -38,7 +38,7 @@ def test_struct_layouts_match_reference():
     assert sph.SphSettings.numParticles.offset == 4 and sph.SphSettings.h.offset == 8
     assert sph.SphSettings.timestep.offset == 28
     assert C.sizeof(sph.SphTimes) == 32 and sph.SphTimes.iters.offset == 24
-    assert C.sizeof(sph.SphOptions) == 24
+    assert C.sizeof(sph.SphOptions) == 28
 
 
 def test_default_settings_match_oracle():

@@ -327,3 +327,75 @@ def test_api_errors():
     sim0.setup(); sim0.simulate(); sim0.simulate()
     assert sim0.getPosition().shape == (0, 3)
     sim0.close()
+
+
+@pytest.fixture
+def morton_oracle():
+    """The oracle's key function is a process-wide switch: Morton inside the test only."""
+    O.set_key_order("morton")
+    yield
+    O.set_key_order("flattened")
+
+
+def _morton(cx, cy, cz):
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(7):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    return spread(cx) | (spread(cy) << 1) | (spread(cz) << 2)
+
+
+@pytest.mark.gpu
+def test_morton_keys_match_the_oracle(morton_oracle):
+    """SPH_KEY_MORTON (BASELINE config 3's ordering; SURVEY.md A.6: the oracle takes the key
+    function as a parameter because it changes the tie order): grid phase and 12 steps of a
+    clustered state against the Morton-keyed oracle, bit for bit; the cell table is indexed
+    by the interleaved bits of the cell coordinates."""
+    pos, vel = clustered_state(30000, 29)
+    s = sph.default_settings(len(pos), False)
+    sim = sph.Simulator(s, sweep="direct", key_order="morton")
+    sim.upload_state(pos, vel)
+    ref = O.OracleSim(len(pos), False)
+    ref.upload(pos, vel)
+    sim.phase("grid")
+    g = sim.download_grid()
+    c = (pos / np.float32(0.1)).astype(np.float32).astype(np.int64)
+    keys = _morton(c[:, 0], c[:, 1], c[:, 2])
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(g["ids"], order.astype(np.uint32))
+    assert np.array_equal(g["keys"], keys[order].astype(np.uint32))
+    assert len(g["cells"]) == 2 ** 21 == O.num_keys(100)
+    sim.phase("density"); sim.phase("force"); sim.phase("readback")
+    ref.step()
+    compare_state(sim, ref, "morton step 1")
+    for _ in range(11):
+        sim.simulate(); ref.step()
+    compare_state(sim, ref, "morton step 12")
+    sim.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_morton_and_flattened_orders_agree_to_rounding(morton_oracle):
+    """The two key functions give different tie orders inside a cell, hence different fp32
+    summation orders: results agree to rounding, not bit for bit (and both are legal
+    outcomes of the reference's racy list order)."""
+    pos = dense_block(14, jitter=0.003, seed=4)
+    s = sph.default_settings(len(pos), False)
+    out = {}
+    for ko in ("flattened", "morton"):
+        sim = sph.Simulator(s, sweep="direct", key_order=ko)
+        sim.upload_state(pos)
+        for _ in range(5):
+            sim.simulate()
+        out[ko] = sim.download_state()
+        sim.close()
+    assert np.allclose(out["morton"]["pos"], out["flattened"]["pos"], rtol=1e-5, atol=1e-6)
+    assert (out["morton"]["rho"] > 1000).sum() > 100
+
+
+@pytest.mark.gpu
+def test_morton_needs_the_direct_sweep():
+    with pytest.raises(sph.SphError, match="MORTON"):
+        sph.Simulator(sph.default_settings(100, True), sweep="list", key_order="morton")
