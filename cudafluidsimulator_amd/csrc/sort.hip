@@ -1,7 +1,8 @@
 // Stable LSD radix sort of (cell key, particle slot) pairs -- the sort-based
 // replacement for the reference's lock-free linked-list grid build
 // (kernelBuildGrid + insertList, simulator.cu:44-55,133-147).  Written for
-// gfx950: 8-bit digits, one 4096-key tile per 256-thread workgroup, each of the
+// gfx950: 8- or 10-bit digits (the 20-bit flattened cell key sorts in TWO 10-bit
+// passes), one 4096-key tile per 256-thread workgroup, each of the
 // four 64-lane waves owns a CONTIGUOUS 1024-key chunk so that (wave, round,
 // lane) order is index order and ranks are stable.  Equal digits inside a wave
 // are found with 8 wave-wide ballots (a 64-bit match mask), the prefix popcount

@@ -111,6 +111,16 @@ namespace {
         }                                                                             \
     } while (0)
 
+// Every entry point that queues work makes the handle's device current first: a host
+// thread that drives several GPUs (include/sph_mgpu.h) or switched devices since
+// sph_create would otherwise launch on the wrong one.
+#define SPH_ON_DEVICE(h)                                                              \
+    do {                                                                              \
+        int d__ = -1;                                                                 \
+        if (hipGetDevice(&d__) != hipSuccess || d__ != (h)->device)                    \
+            HIPCHK(h, hipSetDevice((h)->device));                                     \
+    } while (0)
+
 int fail(sph_handle *h, int code, const std::string &msg) {
     if (h) h->err = msg;
     else g_create_error = msg;
@@ -338,6 +348,7 @@ void drop_step_graphs(sph_handle *h) {
 }
 
 int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
+    SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
     if (n != h->n) return fail(h, SPH_EINVAL, "particle count differs from settings");
     const float hh = h->settings.h;
@@ -470,6 +481,7 @@ extern "C" {
 
 int sph_set_stream(sph_handle *h, void *hip_stream) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->compute));
     if (!h->ownCompute) h->ownCompute = h->compute;
     // NULL is HIP's default ("null") stream -- what torch.cuda.current_stream()
@@ -496,6 +508,7 @@ void *sph_get_stream(sph_handle *h) { return h ? (void *)h->compute : nullptr; }
 int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
                         const uint32_t *thresholds, int nthr, void *bounds_dev_out) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, src_buf, 0, 0, 0);
     if (rc) return rc;
     if (src_offset < 0 || count < 0 || (long long)src_offset + count > h->cap || nthr < 0 ||
@@ -545,6 +558,7 @@ int sph_slab_sort(sph_handle *h, int src_buf, int src_offset, int count,
 int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int count,
                              const uint32_t *thresholds, int nthr, void *bounds_dev_out) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, src_buf, 0, 0, 0);
     if (rc) return rc;
     if (src_offset < 0 || count < 0 || (long long)src_offset + count > h->cap || nthr < 1 ||
@@ -591,6 +605,7 @@ int sph_slab_copy_segments(sph_handle *h, int dst_buf, int nseg, const void *con
                            const void *const *src_vel, const int32_t *counts,
                            const int32_t *dst_offsets) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, dst_buf, 0, 0, 0);
     if (rc) return rc;
     if (nseg < 0 || nseg > 8 || (nseg > 0 && (!src_pos || !src_vel || !counts || !dst_offsets)))
@@ -614,6 +629,7 @@ int sph_slab_copy_segments(sph_handle *h, int dst_buf, int nseg, const void *con
 
 int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
     if (rc) return rc;
     if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
@@ -636,6 +652,7 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
 
 int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
     if (rc) return rc;
     if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
@@ -658,6 +675,7 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
 
 int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all, void *hip_stream) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, buf, i_begin, i_end, n_all);
     if (rc) return rc;
     if (!h->gridValid || h->sorted != buf) return fail(h, SPH_ESTATE, "sph_slab_sort into this buffer first");
@@ -674,6 +692,7 @@ int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_al
 int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, int a1, int b1,
                           int n_all, int last, void *hip_stream) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = slab_range_ok(h, buf, a0, b0 > a0 ? b0 : a0, n_all);
     if (!rc) rc = slab_range_ok(h, buf, a1, b1 > a1 ? b1 : a1, n_all);
     if (rc) return rc;
@@ -888,6 +907,7 @@ int sph_upload_state(sph_handle *h, const float *pos_xyz, const float *vel_xyz, 
 
 int sph_phase_grid(sph_handle *h) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
     if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "grid phase out of order");
     hipStream_t s = h->compute;
@@ -929,6 +949,7 @@ int sph_phase_grid(sph_handle *h) {
 
 int sph_phase_density(sph_handle *h) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (h->phase != 1) return fail(h, SPH_ESTATE, "density phase needs the grid phase first");
     SweepArgs A = make_sweep_args(h);
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
@@ -942,6 +963,7 @@ int sph_phase_density(sph_handle *h) {
 
 int sph_phase_force(sph_handle *h) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (h->phase != 2) return fail(h, SPH_ESTATE, "force phase needs the density phase first");
     SweepArgs A = make_sweep_args(h);
     const int slot = (int)(h->stepIndex & 1);
@@ -963,6 +985,7 @@ int sph_phase_force(sph_handle *h) {
 
 int sph_phase_readback(sph_handle *h) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (h->phase != 3) return fail(h, SPH_ESTATE, "readback needs the force phase first");
     if (h->opt.flags & SPH_FLAG_NO_READBACK) {
         h->stepIndex++;
@@ -1123,6 +1146,7 @@ int sph_step(sph_handle *h, SphTimes *times) {
 
 int sph_apply_click(sph_handle *h, int mx, int my) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (h->opt.sweep == SPH_SWEEP_LINKED)
         return fail(h, SPH_ESTATE, "the click impulse is not available with SPH_SWEEP_LINKED");
     if (!h->gridValid || h->phase != 0 || h->stepIndex == 0)
@@ -1156,6 +1180,7 @@ static_assert(sizeof(SnapshotHeader) == 64, "snapshot header");
 
 int sph_save_state(sph_handle *h, const char *path) {
     if (!h || !path) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
     if (!h->ready || h->phase != 0) return fail(h, SPH_ESTATE, "no complete state to save");
     int rc = sph_sync(h);
@@ -1181,6 +1206,7 @@ int sph_save_state(sph_handle *h, const char *path) {
 
 int sph_load_state(sph_handle *h, const char *path) {
     if (!h || !path) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(h, SPH_EINVAL, std::string("cannot open ") + path);
@@ -1202,6 +1228,13 @@ int sph_load_state(sph_handle *h, const char *path) {
         memcpy(&id, &p4[i].w, 4);
         if (id >= n || seen[id]) return fail(h, SPH_EINVAL, "corrupt snapshot (ids)");
         seen[id] = 1;
+        // the same box / NaN check as sph_upload_state: a corrupt file must not inject NaNs
+        const float x = p4[i].x, y = p4[i].y, z = p4[i].z, hh = h->settings.h;
+        const int cx = (int)(x / hh), cy = (int)(y / hh), czc = (int)(z / hh);
+        const int D = h->P.D;
+        if (!(x == x && y == y && z == z) || cx < 0 || cx >= D || cy < 0 || cy >= D || czc < 0 || czc >= D ||
+            x < 0.f || y < 0.f || z < 0.f || !(v4[i].x == v4[i].x && v4[i].y == v4[i].y && v4[i].z == v4[i].z))
+            return fail(h, SPH_EINVAL, "corrupt snapshot (position outside the simulation box / NaN)");
         const int cz = (int)(p4[i].z / h->settings.h);
         zmin = cz < zmin ? cz : zmin;
         zmax = cz > zmax ? cz : zmax;
@@ -1227,6 +1260,7 @@ int sph_load_state(sph_handle *h, const char *path) {
 
 int sph_sync(sph_handle *h) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->compute));
     HIPCHK(h, hipStreamSynchronize(h->copy));
     return SPH_OK;
@@ -1237,6 +1271,7 @@ int sph_num_table_cells(const sph_handle *h) { return h ? h->P.numCells : SPH_EI
 
 int sph_download_state(sph_handle *h, float *pos, float *vel, float *rho, float *prs) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (!h->ready) return fail(h, SPH_ESTATE, "no state");
     int rc = sph_sync(h);
     if (rc) return rc;
@@ -1262,6 +1297,7 @@ int sph_download_state(sph_handle *h, float *pos, float *vel, float *rho, float 
 
 int sph_download_force(sph_handle *h, float *force_xyz) {
     if (!h || !force_xyz) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (!h->force4) return fail(h, SPH_ESTATE, "create with SPH_FLAG_STORE_FORCE");
     int rc = sph_sync(h);
     if (rc) return rc;
@@ -1284,6 +1320,7 @@ int sph_download_force(sph_handle *h, float *force_xyz) {
 
 int sph_download_grid(sph_handle *h, uint32_t *ids, uint32_t *keys, int32_t *cell_ranges) {
     if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     if (!h->gridValid) return fail(h, SPH_ESTATE, "no grid built yet");
     int rc = sph_sync(h);
     if (rc) return rc;
@@ -1302,6 +1339,7 @@ int sph_download_grid(sph_handle *h, uint32_t *ids, uint32_t *keys, int32_t *cel
 
 int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     if (!h || !out) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
     int rc = sph_sync(h);
     if (rc) return rc;
     for (auto &se : h->ring)

@@ -399,3 +399,27 @@ def test_morton_and_flattened_orders_agree_to_rounding(morton_oracle):
 def test_morton_needs_the_direct_sweep():
     with pytest.raises(sph.SphError, match="MORTON"):
         sph.Simulator(sph.default_settings(100, True), sweep="list", key_order="morton")
+
+
+@pytest.mark.gpu
+def test_corrupt_snapshot_is_rejected(tmp_path):
+    """sph_load_state validates what it reads like sph_upload_state does: a NaN or an
+    out-of-box position in the file must not reach the device."""
+    pos, vel = random_state(3000, 41)
+    sim = sph.Simulator(sph.default_settings(len(pos), False))
+    sim.upload_state(pos, vel)
+    sim.simulate()
+    path = tmp_path / "snap.bin"
+    sim.save_state(path)
+    raw = bytearray(open(path, "rb").read())
+    good = bytes(raw)
+    for value in (np.float32("nan"), np.float32(123.0)):
+        raw = bytearray(good)
+        raw[64 + 16 * 7: 64 + 16 * 7 + 4] = np.float32(value).tobytes()   # x of row 7
+        bad = tmp_path / "bad.bin"
+        open(bad, "wb").write(bytes(raw))
+        with pytest.raises(sph.SphError, match="corrupt snapshot"):
+            sim.load_state(bad)
+    sim.load_state(path)   # the intact file still loads
+    sim.simulate()
+    sim.close()
