@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for ctrs in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps ${PMC_STEPS:-100} --warmup 1 --cpu-steps 0 --no-fast-leg --no-linked-leg "$@" > $OUT/pmc$i.json 2> $OUT/pmc$i.err
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps ${PMC_STEPS:-100} --warmup 1 --cpu-steps 0 --no-fast-leg --no-linked-leg --no-count-replay "$@" > $OUT/pmc$i.json 2> $OUT/pmc$i.err
   echo "pass $i exit $?"
 done
 cd $GRAFT_REPO_ROOT

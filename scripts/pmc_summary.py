@@ -15,6 +15,7 @@ for path in glob.glob(os.path.join(sys.argv[1], "pmc*", "**", "*counter_collecti
             a = acc[k]
             a[0] += float(row["Counter_Value"])
             a[1] += 1
-print("kernel,counter,avg_per_dispatch,dispatches")
+w = csv.writer(sys.stdout)  # kernel names hold commas (template arguments): quoted
+w.writerow(["kernel", "counter", "avg_per_dispatch", "dispatches"])
 for (kern, ctr), (tot, cnt) in sorted(acc.items()):
-    print(f"{kern},{ctr},{tot / cnt:.6g},{cnt}")
+    w.writerow([kern, ctr, f"{tot / cnt:.6g}", cnt])
