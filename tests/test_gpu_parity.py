@@ -423,3 +423,19 @@ def test_corrupt_snapshot_is_rejected(tmp_path):
     sim.load_state(path)   # the intact file still loads
     sim.simulate()
     sim.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 127, 129, 1000])
+def test_odd_particle_counts(n):
+    """Waves with 1..64 valid lanes, a launch of a single wave, no particle at all."""
+    rng = np.random.default_rng(100 + n)
+    pos = rng.uniform(4.0, 4.6, (n, 3)).astype(np.float32)   # dense enough to interact
+    vel = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    for sweep in SWEEPS:
+        sim, ref = make_pair(n, False, sweep, pos=pos, vel=vel)
+        for _ in range(3):
+            sim.simulate(); ref.step()
+        if n:
+            compare_state(sim, ref, f"n={n} {sweep}")
+        sim.close()

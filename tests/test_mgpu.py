@@ -206,3 +206,23 @@ def test_one_object_per_rank_code_path(world, face):
     assert_bit_equal(rho_got, want["rho"], "rho")
     for mg in ranks:
         mg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,world", [(1, 2), (70, 3), (500, 8), (4097, 4)])
+def test_tiny_and_nearly_empty_slabs(n, world):
+    """Slabs that own no particle at all, waves with a handful of valid lanes."""
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(0.2, 9.8, (n, 3)).astype(np.float32)
+    vel = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    settings = sph.default_settings(n, False)
+    want, _ = single_domain(settings, pos, vel, 5)
+    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback")
+    mg.upload_state(pos, vel)
+    for _ in range(5):
+        mg.simulate()
+    got = mg.download_state()
+    assert got["written"] == n
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    assert_bit_equal(got["rho"], want["rho"], "rho")
+    mg.close()
