@@ -17,10 +17,17 @@
 #include "sph_device.h"
 
 #define RS_THREADS 256
-#define RS_ITEMS 16
+// Keys per thread: 16 (4096-key tiles) at large n, 4 (1024-key tiles) below RS_SMALL_N keys,
+// where a launch of 4096-key tiles leaves most of the 256 CUs idle and the per-thread loop of
+// 16 ballot rounds IS the kernel's latency (n = 262,144: 64 tiles).
+#define RS_ITEMS_BIG 16
+#define RS_ITEMS_SMALL 4
+#ifdef RS_SMALL_N_OVERRIDE
+#define RS_SMALL_N RS_SMALL_N_OVERRIDE
+#else
+#define RS_SMALL_N (3 << 19)
+#endif
 #define RS_WAVES (RS_THREADS / SPH_WAVE)
-#define RS_WAVE_TILE (SPH_WAVE * RS_ITEMS)
-#define RS_TILE (RS_THREADS * RS_ITEMS)
 
 // Lanes of this wave whose digit equals mine (among valid lanes).
 template <int BITS>
@@ -47,12 +54,13 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // HASH: first pass of the grid build -- the key is computed from the particle's position
 // here (getGridCell + flattenGridCoord, simulator.cu:57-82) and stored for the scatter
 // passes, instead of a separate hash kernel writing keys and an iota of values.
-template <int BITS, bool HASH>
+template <int BITS, bool HASH, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
     int shift, int numBlocks, DevParams P, const float4 *__restrict__ pos4,
     uint32_t *__restrict__ keysOut) {
     constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
+    constexpr int RS_WAVE_TILE = SPH_WAVE * RS_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t hist[DIG];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 #pragma unroll
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
     __syncthreads();
     const long long base =
         (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_TILE + lane;
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         long long idx = base + r * SPH_WAVE;
         bool valid = idx < n;
@@ -130,13 +138,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(
 
 // IOTA: the values of this pass are the element indices themselves (first pass of the grid
 // build: nothing wrote an iota to memory)
-template <int BITS, bool IOTA>
+template <int BITS, bool IOTA, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
     uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut,
     const uint32_t *__restrict__ blockHist,
     const uint32_t *__restrict__ digitTotal, int n, int shift, int numBlocks) {
     constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
+    constexpr int RS_WAVE_TILE = SPH_WAVE * RS_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t waveCount[RS_WAVES][DIG];
     __shared__ uint32_t digitOff[DIG];
     __shared__ uint32_t tmp[RS_THREADS];
@@ -207,59 +216,65 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     }
 }
 
-size_t sph_sort_workspace_blocks(int n) {
-    return (size_t)((n + RS_TILE - 1) / RS_TILE);
+size_t sph_sort_workspace_blocks(int n) { // for the smallest tile any launch may use
+    return (size_t)((n + RS_THREADS * RS_ITEMS_SMALL - 1) / (RS_THREADS * RS_ITEMS_SMALL));
 }
 
-template <int BITS>
-static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, int numBlocks,
-                       hipStream_t s, const DevParams *P = nullptr, const float4 *pos4 = nullptr) {
+template <int BITS, int ITEMS>
+static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipStream_t s,
+                       const DevParams *P = nullptr, const float4 *pos4 = nullptr) {
+    const int numBlocks = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
     if (pos4) { // first pass of the grid build: hash fused in, values = iota
-        k_radix_hist<BITS, true><<<numBlocks, RS_THREADS, 0, s>>>(nullptr, ws.blockHist, n, shift, numBlocks,
-                                                                  *P, pos4, ws.keys[cur]);
+        k_radix_hist<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(nullptr, ws.blockHist, n, shift,
+                                                                         numBlocks, *P, pos4, ws.keys[cur]);
         k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
-        k_radix_scatter<BITS, true><<<numBlocks, RS_THREADS, 0, s>>>(
+        k_radix_scatter<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
             ws.keys[cur], nullptr, ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist, ws.digitTotal, n, shift,
             numBlocks);
         return;
     }
-    k_radix_hist<BITS, false><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
-                                                               numBlocks, DevParams{}, nullptr, nullptr);
+    k_radix_hist<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
+                                                                      numBlocks, DevParams{}, nullptr, nullptr);
     k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
-    k_radix_scatter<BITS, false><<<numBlocks, RS_THREADS, 0, s>>>(
+    k_radix_scatter<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
         ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist,
         ws.digitTotal, n, shift, numBlocks);
+}
+
+// fewest passes with 8- or 10-bit digits: <=8: 8 | <=10: 10 | <=16: 8+8 |
+// <=20: 10+10 (the 100^3 grid) | <=24: 8+8+8 | <=30: 10+10+10 | else 8-bit passes
+static int digit_bits(int bits) {
+    return ((bits > 8 && bits <= 10) || (bits > 16 && bits <= 20) || (bits > 24 && bits <= 30)) ? 10 : 8;
+}
+
+static int sort_impl(const SortWorkspace &ws, const DevParams *P, const float4 *pos4, int n, int bits,
+                     hipStream_t s) {
+    if (n <= 0) return 0;
+    const int digit = digit_bits(bits);
+    const bool small = n < RS_SMALL_N;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += digit) {
+        const bool first = shift == 0 && pos4;
+        const DevParams *p = first ? P : nullptr;
+        const float4 *q = first ? pos4 : nullptr;
+        if (digit == 10) {
+            if (small) radix_pass<10, RS_ITEMS_SMALL>(ws, cur, n, shift, s, p, q);
+            else radix_pass<10, RS_ITEMS_BIG>(ws, cur, n, shift, s, p, q);
+        } else {
+            if (small) radix_pass<8, RS_ITEMS_SMALL>(ws, cur, n, shift, s, p, q);
+            else radix_pass<8, RS_ITEMS_BIG>(ws, cur, n, shift, s, p, q);
+        }
+        cur ^= 1;
+    }
+    return cur;
 }
 
 // The grid build's sort: cell keys computed from pos4 inside the first histogram pass.
 int sph_sort_cells(const SortWorkspace &ws, const DevParams &P, const float4 *pos4, int n, int bits,
                    hipStream_t s) {
-    if (n <= 0) return 0;
-    const int numBlocks = (n + RS_TILE - 1) / RS_TILE;
-    int digit = 8;
-    if ((bits > 8 && bits <= 10) || (bits > 16 && bits <= 20) || (bits > 24 && bits <= 30)) digit = 10;
-    int cur = 0;
-    for (int shift = 0; shift < bits; shift += digit) {
-        const bool first = shift == 0;
-        if (digit == 10) radix_pass<10>(ws, cur, n, shift, numBlocks, s, first ? &P : nullptr, first ? pos4 : nullptr);
-        else radix_pass<8>(ws, cur, n, shift, numBlocks, s, first ? &P : nullptr, first ? pos4 : nullptr);
-        cur ^= 1;
-    }
-    return cur;
+    return sort_impl(ws, &P, pos4, n, bits, s);
 }
 
 int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s) {
-    if (n <= 0) return 0;
-    const int numBlocks = (n + RS_TILE - 1) / RS_TILE;
-    // fewest passes with 8- or 10-bit digits: <=8: 8 | <=10: 10 | <=16: 8+8 |
-    // <=20: 10+10 (the 100^3 grid) | <=24: 8+8+8 | <=30: 10+10+10 | else 8-bit passes
-    int digit = 8;
-    if ((bits > 8 && bits <= 10) || (bits > 16 && bits <= 20) || (bits > 24 && bits <= 30)) digit = 10;
-    int cur = 0;
-    for (int shift = 0; shift < bits; shift += digit) {
-        if (digit == 10) radix_pass<10>(ws, cur, n, shift, numBlocks, s);
-        else radix_pass<8>(ws, cur, n, shift, numBlocks, s);
-        cur ^= 1;
-    }
-    return cur;
+    return sort_impl(ws, nullptr, nullptr, n, bits, s);
 }
