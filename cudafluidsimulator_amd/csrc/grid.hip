@@ -110,6 +110,140 @@ void sph_launch_classify(const DevParams &P, const float4 *pos4, Thresholds thr,
     k_classify<<<(n + 255) / 256, 256, 0, s>>>(P, pos4, thr, nthr, keys, vals, n);
 }
 
+// ---- slab path: the same stable partition in TWO launches instead of seven (classify, one
+// radix pass = histogram + row scan + scatter, gather, segment bounds, header copy).  At the
+// slab sizes this path sees (a few 10^5 particles per GPU) every launch costs its latency, not
+// its bytes.  Tiles of 1024 particles; a wave owns 256 consecutive ones (4 rounds of 64), so
+// (tile, wave, round, lane) order is index order and ranks are stable.
+//   k_partition_count : class of every particle, per-tile class counts        -> tileCount[tile][8]
+//   k_partition_move  : every tile sums the counts of the tiles before it (a few KB from L2),
+//                       ranks its particles by wave ballots and moves pos4/vel4 to their place;
+//                       tile 0 also writes the bounds (and n) for the message header.
+#define PT_THREADS 256
+#define PT_ITEMS 4
+#define PT_TILE (PT_THREADS * PT_ITEMS)
+
+__device__ __forceinline__ uint32_t partition_class(const DevParams &P, const Thresholds &thr, int nthr, float4 p) {
+    int3 c = grid_cell(P, p.x, p.y, p.z);
+    const uint32_t key = sph_cell_key(P, c.x, c.y, c.z);
+    uint32_t cls = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cls += (k < nthr && key >= thr.v[k]) ? 1u : 0u;
+    return cls;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_partition_count(DevParams P, const float4 *__restrict__ pos4,
+                                                                Thresholds thr, int nthr, int n,
+                                                                int *__restrict__ tileCount) {
+    __shared__ int cnt[9];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 9) cnt[t] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * PT_TILE + (long long)w * (SPH_WAVE * PT_ITEMS) + lane;
+#pragma unroll
+    for (int r = 0; r < PT_ITEMS; ++r) {
+        const long long idx = base + r * SPH_WAVE;
+        const bool valid = idx < n;
+        const uint32_t cls = valid ? partition_class(P, thr, nthr, pos4[idx]) : 0xFFu;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { // wave-uniform trip count; nthr <= 8 => classes 0..8
+            const unsigned long long m = __ballot(valid && cls == (uint32_t)c);
+            if (lane == 0 && m) atomicAdd(&cnt[c], (int)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (t < 9) tileCount[(size_t)blockIdx.x * 9 + t] = cnt[t];
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_partition_move(DevParams P, const float4 *__restrict__ pos_in,
+                                                               const float4 *__restrict__ vel_in,
+                                                               float4 *__restrict__ pos_out,
+                                                               float4 *__restrict__ vel_out, Thresholds thr,
+                                                               int nthr, int n, const int *__restrict__ tileCount,
+                                                               int numTiles, int *__restrict__ bounds_out) {
+    __shared__ int before[9], total[9], classBase[10];
+    __shared__ int waveCnt[PT_THREADS / SPH_WAVE][9];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 9) before[t] = total[t] = 0;
+    if (t < 36) waveCnt[t / 9][t % 9] = 0;
+    __syncthreads();
+    // class c = t % 9 (threads 0..251: 28 rows of 9), tiles strided by 28
+    if (t < 252) {
+        const int c = t % 9;
+        int b = 0, a = 0;
+        for (int q = t / 9; q < numTiles; q += 28) {
+            const int v = tileCount[(size_t)q * 9 + c];
+            a += v;
+            b += q < (int)blockIdx.x ? v : 0;
+        }
+        atomicAdd(&before[c], b);
+        atomicAdd(&total[c], a);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int c = 0; c < 9; ++c) {
+            classBase[c] = run;
+            run += total[c];
+        }
+        classBase[9] = run;
+        if (blockIdx.x == 0 && bounds_out) { // bounds[k] = #particles of class <= k; then n
+            for (int k = 0; k < nthr; ++k) bounds_out[k] = classBase[k + 1];
+            bounds_out[nthr] = n;
+        }
+    }
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * PT_TILE + (long long)w * (SPH_WAVE * PT_ITEMS) + lane;
+    float4 p[PT_ITEMS], v[PT_ITEMS];
+    uint32_t cls[PT_ITEMS];
+    int rank[PT_ITEMS]; // rank inside this wave's 256 particles, among its class
+#pragma unroll
+    for (int r = 0; r < PT_ITEMS; ++r) {
+        const long long idx = base + r * SPH_WAVE;
+        const bool valid = idx < n;
+        p[r] = valid ? pos_in[idx] : make_float4(0, 0, 0, 0);
+        v[r] = valid ? vel_in[idx] : make_float4(0, 0, 0, 0);
+        cls[r] = valid ? partition_class(P, thr, nthr, p[r]) : 0xFFu;
+        rank[r] = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const unsigned long long m = __ballot(valid && cls[r] == (uint32_t)c);
+            if (cls[r] == (uint32_t)c)
+                rank[r] = waveCnt[w][c] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0 && m) waveCnt[w][c] += (int)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PT_ITEMS; ++r) {
+        const long long idx = base + r * SPH_WAVE;
+        if (idx < n) {
+            const int c = (int)cls[r];
+            int off = 0; // particles of class c in the waves of this tile before mine
+            for (int q = 0; q < w; ++q) off += waveCnt[q][c];
+            const int dst = classBase[c] + before[c] + off + rank[r];
+            pos_out[dst] = p[r];
+            vel_out[dst] = v[r];
+        }
+    }
+}
+
+void sph_launch_partition(const DevParams &P, const float4 *pos_in, const float4 *vel_in, float4 *pos_out,
+                          float4 *vel_out, Thresholds thr, int nthr, int n, int *tileCount, int *bounds_dev,
+                          hipStream_t s) {
+    const int tiles = n > 0 ? (n + PT_TILE - 1) / PT_TILE : 1;
+    if (n > 0) k_partition_count<<<tiles, PT_THREADS, 0, s>>>(P, pos_in, thr, nthr, n, tileCount);
+    // (n == 0: one tile that finds no particle still writes the bounds: all zero)
+    if (n <= 0) (void)hipMemsetAsync(tileCount, 0, 9 * sizeof(int), s);
+    k_partition_move<<<tiles, PT_THREADS, 0, s>>>(P, pos_in, vel_in, pos_out, vel_out, thr, nthr, n, tileCount, tiles,
+                                                  bounds_dev);
+}
+
+size_t sph_partition_tiles(int n) { return (size_t)((n + PT_TILE - 1) / PT_TILE + 1); }
+
 __global__ __launch_bounds__(256) void k_gather_plain(const float4 *__restrict__ pos_in,
                                                       const float4 *__restrict__ vel_in,
                                                       const uint32_t *__restrict__ perm,

@@ -90,6 +90,7 @@ struct sph_handle {
     bool external = false;  // pos4/vel4 are caller-owned (sph_bind_buffers)
     hipStream_t ownCompute = nullptr;
     int *boundsDev = nullptr, *boundsHost = nullptr;
+    int *partTiles = nullptr; // slab partition: class counts per 1024-particle tile
     PairEvent pairs[kPairRing];
     int pairHead = 0;
     int zLayers = 0;        // occupied z-layers of the (owned) particles: sizes xcd_tile()'s chunks
@@ -289,6 +290,7 @@ int alloc_device(sph_handle *h) {
         HIPCHK(h, hipMemset(h->maskCursor, 0, kCursorBytes));
     }
     HIPCHK(h, hipMalloc(&h->boundsDev, 16 * sizeof(int)));
+    HIPCHK(h, hipMalloc(&h->partTiles, sph_partition_tiles((int)cap) * 9 * sizeof(int)));
     HIPCHK(h, hipHostMalloc(&h->boundsHost, 8 * sizeof(int), hipHostMallocDefault));
     for (auto &pe : h->pairs) {
         HIPCHK(h, hipEventCreate(&pe.a));
@@ -571,15 +573,11 @@ int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int cou
     if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
     Thresholds T{};
     for (int k = 0; k < nthr; ++k) T.v[k] = thresholds[k];
-    sph_launch_classify(h->P, h->pos4[src_buf] + src_offset, T, nthr, h->ws.keys[0], h->ws.vals[0],
-                        count, s);
-    int res = sph_sort_pairs(h->ws, count, 4, s); // classes 0..8: one radix pass, stable
-    sph_launch_gather_plain(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
-                            h->ws.vals[res], h->pos4[src_buf ^ 1], h->vel4[src_buf ^ 1], count, s);
+    // two launches (count per tile, move): grid.hip
+    sph_launch_partition(h->P, h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
+                         h->pos4[src_buf ^ 1], h->vel4[src_buf ^ 1], T, nthr, count, h->partTiles,
+                         h->boundsDev, s);
     HIPCHK(h, hipEventRecord(pe->b, s));
-    Thresholds C{};
-    for (int k = 0; k < nthr; ++k) C.v[k] = (uint32_t)(k + 1);
-    sph_launch_lower_bounds(h->ws.keys[res], count, C, nthr, h->boundsDev, s); // also [nthr] = count
     if (bounds_dev_out)
         HIPCHK(h, hipMemcpyAsync(bounds_dev_out, h->boundsDev, (nthr + 1) * sizeof(int),
                                  hipMemcpyDeviceToDevice, s));
@@ -880,6 +878,7 @@ void sph_destroy(sph_handle *h) {
     if (h->maskOff) (void)hipFree(h->maskOff);
     if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
+    if (h->partTiles) (void)hipFree(h->partTiles);
     if (h->boundsHost) (void)hipHostFree(h->boundsHost);
     for (auto &pe : h->pairs) {
         if (pe.a) (void)hipEventDestroy(pe.a);

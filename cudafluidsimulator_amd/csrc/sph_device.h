@@ -93,6 +93,11 @@ void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr,
                              int *bounds_dev, hipStream_t s);
 void sph_launch_classify(const DevParams &P, const float4 *pos4, Thresholds thr, int nthr,
                          uint32_t *keys, uint32_t *vals, int n, hipStream_t s);
+// stable partition of [0, n) by key class in two launches (tileCount: sph_partition_tiles(n) x 9 ints)
+void sph_launch_partition(const DevParams &P, const float4 *pos_in, const float4 *vel_in, float4 *pos_out,
+                          float4 *vel_out, Thresholds thr, int nthr, int n, int *tileCount, int *bounds_dev,
+                          hipStream_t s);
+size_t sph_partition_tiles(int n);
 void sph_launch_gather_plain(const float4 *pos_in, const float4 *vel_in, const uint32_t *perm,
                              float4 *pos_out, float4 *vel_out, int n, hipStream_t s);
 struct SegmentTable {
