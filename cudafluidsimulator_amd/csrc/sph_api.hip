@@ -816,7 +816,10 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
         return fail(nullptr, SPH_EINVAL, "SPH_SWEEP_LINKED is single-domain only");
     }
     h->n = settings->numParticles;
-    h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
+    // a slab handle (caller-owned streams) is sized by its capacity alone: a GPU of an N-GPU run
+    // holds ~1/N of the numParticles its settings name
+    if ((h->opt.flags & SPH_FLAG_EXTERNAL_STATE) && h->opt.capacity > 0) h->cap = h->opt.capacity;
+    else h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
     if (const char *e = getenv("SPH_TILE_CHUNK")) h->tileChunkEnv = atoi(e); // tuning studies
     fill_params(h);
     int rc = SPH_OK;
@@ -907,6 +910,7 @@ int sph_upload_state(sph_handle *h, const float *pos_xyz, const float *vel_xyz, 
 int sph_phase_grid(sph_handle *h) {
     if (!h) return SPH_EINVAL;
     SPH_ON_DEVICE(h);
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
     if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "grid phase out of order");
     hipStream_t s = h->compute;
@@ -1067,6 +1071,7 @@ int capture_step_graph(sph_handle *h, int slot) {
 
 int sph_step(sph_handle *h, SphTimes *times) {
     if (!h) return SPH_EINVAL;
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
     if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "a step split into phases is still open");
     int rc;
@@ -1146,6 +1151,7 @@ int sph_step(sph_handle *h, SphTimes *times) {
 int sph_apply_click(sph_handle *h, int mx, int my) {
     if (!h) return SPH_EINVAL;
     SPH_ON_DEVICE(h);
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (h->opt.sweep == SPH_SWEEP_LINKED)
         return fail(h, SPH_ESTATE, "the click impulse is not available with SPH_SWEEP_LINKED");
     if (!h->gridValid || h->phase != 0 || h->stepIndex == 0)
@@ -1271,6 +1277,7 @@ int sph_num_table_cells(const sph_handle *h) { return h ? h->P.numCells : SPH_EI
 int sph_download_state(sph_handle *h, float *pos, float *vel, float *rho, float *prs) {
     if (!h) return SPH_EINVAL;
     SPH_ON_DEVICE(h);
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->ready) return fail(h, SPH_ESTATE, "no state");
     int rc = sph_sync(h);
     if (rc) return rc;
@@ -1297,6 +1304,7 @@ int sph_download_state(sph_handle *h, float *pos, float *vel, float *rho, float 
 int sph_download_force(sph_handle *h, float *force_xyz) {
     if (!h || !force_xyz) return SPH_EINVAL;
     SPH_ON_DEVICE(h);
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->force4) return fail(h, SPH_ESTATE, "create with SPH_FLAG_STORE_FORCE");
     int rc = sph_sync(h);
     if (rc) return rc;
@@ -1320,6 +1328,7 @@ int sph_download_force(sph_handle *h, float *force_xyz) {
 int sph_download_grid(sph_handle *h, uint32_t *ids, uint32_t *keys, int32_t *cell_ranges) {
     if (!h) return SPH_EINVAL;
     SPH_ON_DEVICE(h);
+    if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->gridValid) return fail(h, SPH_ESTATE, "no grid built yet");
     int rc = sph_sync(h);
     if (rc) return rc;

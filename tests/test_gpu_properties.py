@@ -108,3 +108,28 @@ def test_config5_67108864_dense_lattice_extension():
     b.simulate()
     assert_bit_equal(b.download_state()["pos"], pos_a, "list vs lds @67M dense lattice")
     b.close()
+
+
+def test_config5_67108864_eight_slabs_equal_single_domain():
+    """BASELINE.json configs[4] at FULL size through the C++ multi-GPU driver: eight
+    z-slabs (the loopback transport puts them on this one GPU) of the 67,108,864-particle
+    dense lattice -- 71 particles per cell, pressure on from step 1, halo layers of ~0.68 M
+    particles -- against the single domain, one step, bit for bit."""
+    from cudafluidsimulator_amd import mgpu as M
+    n = 67108864
+    s = sph.default_settings(n, False)
+    mg = M.MultiGpuSimulator(s, world=8, transport="loopback")
+    mg.setup()
+    mg.simulate()
+    got = mg.download_state()
+    st = mg.stats()
+    mg.close()
+    assert got["written"] == n and st.host_syncs == 1
+    a = sph.Simulator(s, sweep="list")
+    a.setup()
+    a.simulate()
+    want = a.download_state()
+    a.close()
+    assert (want["rho"] > 1000).sum() > n // 4
+    assert_bit_equal(got["pos"], want["pos"], "67M dense lattice, 8 slabs vs single domain: pos")
+    assert_bit_equal(got["rho"], want["rho"], "67M dense lattice, 8 slabs vs single domain: rho")
