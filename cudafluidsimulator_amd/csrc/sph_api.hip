@@ -264,12 +264,12 @@ int alloc_device(sph_handle *h) {
         // 27 x particles per cell (about half the cells of the box hold particles with
         // the reference initialisers) and grow ~4.7x as the fluid settles (measured at
         // n = 4,194,304: 217 at step 1, 1011 at step 100, i.e. 9 -> 36 words per lane
-        // plus up to one partly filled word per run).  The pool is sized for 4x the
+        // plus up to two partly filled words per run).  The pool is sized for 5x the
         // initial fill + the per-run slack, never more than 40 % of the device memory
         // that is free now; a wave that finds it exhausted falls back to testing every
         // candidate again in the force sweep (k_force_fallback: same results, slower).
         const double ppc = (double)cap / (0.5 * (double)h->P.numCells);
-        const double wordsPerLane = 4.0 * (27.0 * ppc / 32.0) + 12.0;
+        const double wordsPerLane = 5.0 * (27.0 * ppc / 32.0) + 24.0;
         unsigned long long quads = (unsigned long long)((double)cap * wordsPerLane * 0.5 * 1.25);
         if (quads < (1ull << 20)) quads = 1ull << 20;
         size_t freeB = 0, totalB = 0;

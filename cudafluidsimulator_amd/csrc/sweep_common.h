@@ -11,7 +11,10 @@
 #define SW_UNROLL 4 // candidates per trip of a lock-step walk
 #endif
 #ifndef SW_CAP
-#define SW_CAP 256  // staged candidates per chunk per wave (4 KiB)
+#define SW_CAP 384  // staged candidates per run per wave (6 KiB).  Measured over the 100-step headline
+                    // run (density sweep, ms): 256: 0.786, 384: 0.718, 512: 0.750, 640: 0.827, 1024: 1.128 --
+                    // late in the run 40-60 % of the candidates sit in runs longer than 256 and are walked
+                    // from global memory; beyond 384 the lost resident waves cost more than that
 #endif
 #ifndef SW_QCAP
 // hit-FIFO entries per lane (8 KiB per wave).  Measured at n = 4,194,304: 16 entries

@@ -320,6 +320,12 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
                 // about half the trips and 0.5 % of the kernel: not kept)
                 // (two copies of the loop rather than one with a select in it: joining
                 // the LDS and the global candidates cost 20 register moves per trip)
+                // (measured, round 2: staging a union longer than the slice chunk by chunk --
+                // chunks aligned to absolute multiples of 32, every lane walking every chunk --
+                // instead of the global-memory walk below: bit-identical, but the extra trips
+                // (union vs own range) cost what the gathers cost: density 0.786 -> 0.884 ms over
+                // the 100 steps, 1.72 -> 1.69 at steps 81..100.  A larger slice helps instead:
+                // SW_CAP 256 / 384 / 512 / 640 / 1024: 0.786 / 0.718 / 0.750 / 0.827 / 1.128.)
                 if (R.staged) {
                     for (; __ballot(k < len); k += SW_UNROLL) {
                         float4 pj[SW_UNROLL];
