@@ -57,6 +57,9 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_EXP_LDSONLY
 #define SL_EXP_LDSONLY 0
 #endif
+#ifndef SL_TRIVIAL_TEST
+#define SL_TRIVIAL_TEST 0
+#endif
 #ifndef SL_PV8
 #define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
@@ -514,6 +517,23 @@ void k_force_list(DevParams P, SweepArgs A) {
     p = win[2 * ((j) & (SL_WINDOW - 1))];                                      \
     v = win[2 * ((j) & (SL_WINDOW - 1)) + 1];                                  \
     body(p, v);
+#elif SL_TRIVIAL_TEST
+        // experiment: a pair with no pressure on either side and no relative velocity adds
+        // exactly +-0 to the force (fPressure = -0, dv = +0): fetch the velocity half first and
+        // fetch the position half / run the body only for the other pairs (here: synchronously)
+#define SL_FETCH(j, p, v)                                                      \
+    if ((unsigned)((j)-w0) >= (unsigned)wlen) v = A.pv8[2 * (size_t)(j) + 1];
+#define SL_USE(j, p, v)                                                        \
+    {                                                                          \
+        const bool inw = (unsigned)((j)-w0) < (unsigned)wlen;                  \
+        if (inw) v = win[2 * ((j)-w0) + 1];                                    \
+        const float prs_j = fmaxf(0.f, SPH_GAS_CONSTANT * (v.w - SPH_REST_DENSITY)); \
+        const bool triv = (prs_i + prs_j == 0.f) && v.x == vi.x && v.y == vi.y && v.z == vi.z; \
+        if (!triv) {                                                           \
+            p = inw ? win[2 * ((j)-w0)] : A.pv8[2 * (size_t)(j)];              \
+            body(p, v);                                                        \
+        }                                                                      \
+    }
 #elif SL_WINDOW
         // fetch: issue the global gather only for lanes whose hit is outside the
         // window (fewer active lanes = fewer addresses for the TA); the LDS copy is
