@@ -86,9 +86,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
         } else {
             key = valid ? keys[idx] : 0u;
         }
-        uint32_t d = (key >> shift) & (DIG - 1);
-        unsigned long long m = match_digit<BITS>(d, valid);
-        if (valid && lanes_below(m) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(m));
+        // Counting needs no ranks: one LDS atomic per key, except when the whole wave holds
+        // one digit (already-ordered streams: -i grid, the slab sorts), where the 64-way
+        // same-address add would serialise -- then one lane adds the wave's count.
+        const uint32_t d = (key >> shift) & (DIG - 1);
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        const unsigned long long live = __ballot(valid);
+        if (__ballot(valid && d != d0) == 0ull && (live & 1ull)) {
+            if (lane == 0) atomicAdd(&hist[d0], (uint32_t)__popcll(live));
+        } else if (valid) {
+            atomicAdd(&hist[d], 1u);
+        }
     }
     __syncthreads();
 #pragma unroll

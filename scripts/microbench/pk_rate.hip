@@ -1,6 +1,7 @@
 // Are packed fp32 VALU ops (v_pk_mul_f32 / v_pk_add_f32) a throughput win on gfx950?
 // Compares 8 independent scalar mul/add chains with 4 packed float2 chains doing
-// the same arithmetic.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off pk_rate.hip
+// the same arithmetic.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize pk_rate.hip
+// (without -fno-slp-vectorize hipcc packs the "scalar" chains into v_pk_* too)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float float2v __attribute__((ext_vector_type(2)));
