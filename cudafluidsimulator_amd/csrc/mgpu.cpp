@@ -887,6 +887,12 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
     for (auto &sl : m->slabs) {
         HIPM(m, hipSetDevice(sl.device));
         const int a = sl.has_dn ? sl.e_lo : sl.i0, b = sl.has_up ? sl.s_hi : sl.i1;
+        if (m->shared_stream) {
+            // loopback / self transport: exchange B was delivered in stream order, there is
+            // nothing to overlap -- the whole slab in ONE launch (one tail instead of two)
+            SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb, nullptr));
+            SPHM(m, sl, sph_slab_force_ranges(sl.h, sl.sbuf, sl.i0, sl.i0, sl.i1, 0, 0, sl.n_comb, 1, nullptr));
+        } else {
         // interior layers: every neighbour is an owned row -> no need to wait for exchange B
         SPHM(m, sl, sph_slab_force_ranges(sl.h, sl.sbuf, sl.i0, a, b, 0, 0, sl.n_comb, 0, nullptr));
         // the two boundary layers in ONE launch once the halo densities are in: on a stream
@@ -899,6 +905,7 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
         if (sl.bnd) {
             HIPM(m, hipEventRecord(sl.evBnd, sl.bnd));
             HIPM(m, hipStreamWaitEvent(sl.s, sl.evBnd, 0));
+        }
         }
         if (times) HIPM(m, hipEventRecord(sl.evT[2], sl.s));
         sl.cur = sl.sbuf ^ 1;
