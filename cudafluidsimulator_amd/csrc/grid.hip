@@ -45,7 +45,7 @@ void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
 // into sorted order (16-B gathers, 16-B coalesced stores) and write cell
 // boundaries.  A lane compares its key with its wave neighbours through DPP
 // shuffles; only lanes 0 and 63 touch memory for the key next door.
-// cellRange must have been cleared (hipMemsetAsync) beforehand: empty cells
+// cellRange must have been cleared beforehand (the first sort pass does it): empty cells
 // keep {0,0}.
 __global__ __launch_bounds__(256) void k_gather_cells(
     const float4 *__restrict__ pos_in, const float4 *__restrict__ vel_in,

@@ -58,13 +58,16 @@ template <int BITS, bool HASH, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
     int shift, int numBlocks, DevParams P, const float4 *__restrict__ pos4,
-    uint32_t *__restrict__ keysOut) {
+    uint32_t *__restrict__ keysOut, int2 *__restrict__ zeroTable, int zeroCount) {
     constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
     constexpr int RS_WAVE_TILE = SPH_WAVE * RS_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
     __shared__ uint32_t hist[DIG];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 #pragma unroll
     for (int q = 0; q < PER; ++q) hist[t + q * RS_THREADS] = 0;
+    if (HASH) // kernelResetGrid (simulator.cu:321-326): the cell table is cleared here, not by a launch of its own
+        for (int k = blockIdx.x * RS_THREADS + t; k < zeroCount; k += numBlocks * RS_THREADS)
+            zeroTable[k] = make_int2(0, 0);
     __syncthreads();
     const long long base =
         (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_TILE + lane;
@@ -230,11 +233,13 @@ size_t sph_sort_workspace_blocks(int n) { // for the smallest tile any launch ma
 
 template <int BITS, int ITEMS>
 static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipStream_t s,
-                       const DevParams *P = nullptr, const float4 *pos4 = nullptr) {
+                       const DevParams *P = nullptr, const float4 *pos4 = nullptr, int2 *zeroTable = nullptr,
+                       int zeroCount = 0) {
     const int numBlocks = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
     if (pos4) { // first pass of the grid build: hash fused in, values = iota
         k_radix_hist<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(nullptr, ws.blockHist, n, shift,
-                                                                         numBlocks, *P, pos4, ws.keys[cur]);
+                                                                         numBlocks, *P, pos4, ws.keys[cur],
+                                                                         zeroTable, zeroCount);
         k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
         k_radix_scatter<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
             ws.keys[cur], nullptr, ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist, ws.digitTotal, n, shift,
@@ -242,7 +247,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
         return;
     }
     k_radix_hist<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
-                                                                      numBlocks, DevParams{}, nullptr, nullptr);
+                                                                      numBlocks, DevParams{}, nullptr, nullptr, nullptr, 0);
     k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
     k_radix_scatter<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
         ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist,
@@ -256,8 +261,11 @@ static int digit_bits(int bits) {
 }
 
 static int sort_impl(const SortWorkspace &ws, const DevParams *P, const float4 *pos4, int n, int bits,
-                     hipStream_t s) {
-    if (n <= 0) return 0;
+                     hipStream_t s, int2 *zeroTable = nullptr, int zeroCount = 0) {
+    if (n <= 0) {
+        if (zeroTable && zeroCount > 0) (void)hipMemsetAsync(zeroTable, 0, (size_t)zeroCount * sizeof(int2), s);
+        return 0;
+    }
     const int digit = digit_bits(bits);
     const bool small = n < RS_SMALL_N;
     int cur = 0;
@@ -266,21 +274,22 @@ static int sort_impl(const SortWorkspace &ws, const DevParams *P, const float4 *
         const DevParams *p = first ? P : nullptr;
         const float4 *q = first ? pos4 : nullptr;
         if (digit == 10) {
-            if (small) radix_pass<10, RS_ITEMS_SMALL>(ws, cur, n, shift, s, p, q);
-            else radix_pass<10, RS_ITEMS_BIG>(ws, cur, n, shift, s, p, q);
+            if (small) radix_pass<10, RS_ITEMS_SMALL>(ws, cur, n, shift, s, p, q, zeroTable, zeroCount);
+            else radix_pass<10, RS_ITEMS_BIG>(ws, cur, n, shift, s, p, q, zeroTable, zeroCount);
         } else {
-            if (small) radix_pass<8, RS_ITEMS_SMALL>(ws, cur, n, shift, s, p, q);
-            else radix_pass<8, RS_ITEMS_BIG>(ws, cur, n, shift, s, p, q);
+            if (small) radix_pass<8, RS_ITEMS_SMALL>(ws, cur, n, shift, s, p, q, zeroTable, zeroCount);
+            else radix_pass<8, RS_ITEMS_BIG>(ws, cur, n, shift, s, p, q, zeroTable, zeroCount);
         }
         cur ^= 1;
     }
     return cur;
 }
 
-// The grid build's sort: cell keys computed from pos4 inside the first histogram pass.
+// The grid build's sort: cell keys computed from pos4 inside the first histogram pass,
+// which also clears the cell table (cellRange[0..numCells)) for k_gather_cells.
 int sph_sort_cells(const SortWorkspace &ws, const DevParams &P, const float4 *pos4, int n, int bits,
-                   hipStream_t s) {
-    return sort_impl(ws, &P, pos4, n, bits, s);
+                   hipStream_t s, int2 *cellRange, int numCells) {
+    return sort_impl(ws, &P, pos4, n, bits, s, cellRange, numCells);
 }
 
 int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s) {

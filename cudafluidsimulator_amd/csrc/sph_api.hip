@@ -519,8 +519,8 @@ int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
     hipStream_t s = h->compute;
     PairEvent *pe = nullptr;
     if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
-    int res = sph_sort_cells(h->ws, h->P, h->pos4[src_buf] + src_offset, count, key_bits(h), s);
+    int res = sph_sort_cells(h->ws, h->P, h->pos4[src_buf] + src_offset, count, key_bits(h), s, h->cellRange,
+                             h->P.numCells); // (clears the cell table too)
     sph_launch_gather(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
                       h->ws.vals[res], h->ws.keys[res], h->pos4[src_buf ^ 1],
                       h->vel4[src_buf ^ 1], h->pv8, h->cellRange, count, s);
@@ -934,10 +934,10 @@ int sph_phase_grid(sph_handle *h) {
         h->phase = 1;
         return SPH_OK;
     }
-    // kernelResetGrid (simulator.cu:321-326,492-495): 8 MB memset, not 10^6 blocks
-    HIPCHK(h, hipMemsetAsync(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2), s));
-    if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s)); // (the hash is part of the first sort pass)
-    int res = sph_sort_cells(h->ws, h->P, h->pos4[c], n, key_bits(h), s);
+    // kernelResetGrid (simulator.cu:321-326,492-495) and the cell hash are both part of the
+    // first sort pass: no launch of their own
+    if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
+    int res = sph_sort_cells(h->ws, h->P, h->pos4[c], n, key_bits(h), s, h->cellRange, h->P.numCells);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
     sph_launch_gather(h->pos4[c], h->vel4[c], h->ws.vals[res], h->ws.keys[res],
                       h->pos4[c ^ 1], h->vel4[c ^ 1], h->pv8, h->cellRange, n, s);

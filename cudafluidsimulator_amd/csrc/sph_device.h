@@ -76,9 +76,10 @@ size_t sph_sort_workspace_blocks(int n);
 int sph_sort_pairs(const SortWorkspace &ws, int n, int bits, hipStream_t s);
 struct DevParams;
 // Same, for the grid build: the keys are the flattened cell indices of pos4[0..n), computed
-// inside the first histogram pass (no separate hash kernel, no iota of values in memory).
+// inside the first histogram pass (no separate hash kernel, no iota of values in memory);
+// that pass also zeroes cellRange[0..numCells) (kernelResetGrid) for k_gather_cells.
 int sph_sort_cells(const SortWorkspace &ws, const DevParams &P, const float4 *pos4, int n, int bits,
-                   hipStream_t s);
+                   hipStream_t s, int2 *cellRange, int numCells);
 
 // ---- grid build (grid.hip) ----
 void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
