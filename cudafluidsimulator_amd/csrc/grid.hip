@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     uint32_t src = perm[i];
     const float4 p = pos_in[src], v = vel_in[src];
     pos_out[i] = p;
-    vel_out[i] = v;
+    if (vel_out) vel_out[i] = v; // (null: the list sweeps read velocities from pv8 only)
     if (pv8) { // interleaved copy for the list sweep's force gathers (one line per hit)
         pv8[2 * (size_t)i] = p;
         pv8[2 * (size_t)i + 1] = v;

@@ -939,8 +939,10 @@ int sph_phase_grid(sph_handle *h) {
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
     int res = sph_sort_cells(h->ws, h->P, h->pos4[c], n, key_bits(h), s, h->cellRange, h->P.numCells);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
+    // the list sweeps take velocities from the interleaved records: no sorted vel4 copy
+    float4 *velSorted = (h->opt.sweep == SPH_SWEEP_LIST && h->pv8) ? nullptr : h->vel4[c ^ 1];
     sph_launch_gather(h->pos4[c], h->vel4[c], h->ws.vals[res], h->ws.keys[res],
-                      h->pos4[c ^ 1], h->vel4[c ^ 1], h->pv8, h->cellRange, n, s);
+                      h->pos4[c ^ 1], velSorted, h->pv8, h->cellRange, n, s);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[3], s));
     HIPCHK(h, hipGetLastError());
     h->sorted = c ^ 1;
