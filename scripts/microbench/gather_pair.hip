@@ -11,7 +11,6 @@
 #include <vector>
 
 #define TRIPS 46
-#define HOOD 2304
 
 __device__ __forceinline__ unsigned lcg(unsigned &s) {
     s = s * 1664525u + 1013904223u;
@@ -19,12 +18,24 @@ __device__ __forceinline__ unsigned lcg(unsigned &s) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k(const float4 *__restrict__ tab, float *__restrict__ out, int nrec) {
+__global__ __launch_bounds__(64) void k(const float4 *__restrict__ tab, float *__restrict__ out, int nrec, int HOOD) {
     const int lane = threadIdx.x, wave = blockIdx.x;
     const int base = min(max(wave * 64 - HOOD / 2, 0), nrec - HOOD);
     unsigned s = wave * 64u + lane + 12345u;
     float acc = 0.f;
-    if (MODE == 0) {
+    if (MODE == 2) { // position half only: one gather per trip
+        int j0 = base + lcg(s) % HOOD, j1 = base + lcg(s) % HOOD;
+        float4 p0 = tab[2 * (size_t)j0], p1 = tab[2 * (size_t)j1];
+        for (int t = 0; t < TRIPS; t += 2) {
+            acc += p0.x * p0.y + p0.z * p0.w;
+            j0 = base + lcg(s) % HOOD;
+            p0 = tab[2 * (size_t)j0];
+            acc += p1.x * p1.y + p1.z * p1.w;
+            j1 = base + lcg(s) % HOOD;
+            p1 = tab[2 * (size_t)j1];
+        }
+        acc += p0.x + p1.x;
+    } else if (MODE == 0) {
         int j0 = base + lcg(s) % HOOD, j1 = base + lcg(s) % HOOD;
         float4 p0 = tab[2 * (size_t)j0], v0 = tab[2 * (size_t)j0 + 1];
         float4 p1 = tab[2 * (size_t)j1], v1 = tab[2 * (size_t)j1 + 1];
@@ -94,23 +105,27 @@ int main() {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     std::vector<float> r0((size_t)waves * 64), r1((size_t)waves * 64);
-    for (int rep = 0; rep < 3; ++rep) {
-        float ms[2];
-        for (int mode = 0; mode < 2; ++mode) {
-            (void)hipEventRecord(e0);
-            for (int q = 0; q < 5; ++q) {
-                if (mode == 0) k<0><<<waves, 64>>>(tab, out, nrec);
-                else k<1><<<waves, 64>>>(tab, out, nrec);
+    // neighbourhood sizes: 64 records = 2 KB (L1-resident), 2,304 = 74 KB (the force sweep's), 65,536 = 2 MB (L2 only)
+    for (int hood : {64, 512, 2304, 65536}) {
+        float ms[3];
+        for (int mode = 0; mode < 3; ++mode) {
+            for (int rep = 0; rep < 2; ++rep) { // second timing counts
+                (void)hipEventRecord(e0);
+                for (int q = 0; q < 5; ++q) {
+                    if (mode == 0) k<0><<<waves, 64>>>(tab, out, nrec, hood);
+                    else if (mode == 1) k<1><<<waves, 64>>>(tab, out, nrec, hood);
+                    else k<2><<<waves, 64>>>(tab, out, nrec, hood);
+                }
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms[mode], e0, e1);
             }
-            (void)hipEventRecord(e1);
-            (void)hipEventSynchronize(e1);
-            (void)hipEventElapsedTime(&ms[mode], e0, e1);
-            (void)hipMemcpy(mode ? r1.data() : r0.data(), out, r0.size() * 4, hipMemcpyDeviceToHost);
+            if (mode < 2) (void)hipMemcpy(mode ? r1.data() : r0.data(), out, r0.size() * 4, hipMemcpyDeviceToHost);
         }
         size_t bad = 0;
         for (size_t i = 0; i < r0.size(); ++i) bad += r0[i] != r1[i];
-        printf("rep %d: own-record gathers %.3f ms/launch, lane-pair gathers %.3f ms/launch (results differ in %zu lanes)\n",
-               rep, ms[0] / 5, ms[1] / 5, bad);
+        printf("neighbourhood %6d records: own-record gathers %.3f ms/launch | lane-pair gathers %.3f (results differ in %zu lanes) | "
+               "position half only %.3f\n", hood, ms[0] / 5, ms[1] / 5, bad, ms[2] / 5);
     }
     return 0;
 }
