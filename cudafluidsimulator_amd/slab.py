@@ -431,18 +431,33 @@ class DistTransport:
             for x, buf in landing:
                 x.copy_(buf)
 
+    def abort(self):
+        """This rank cannot go on (capacity, a particle beyond the halo layer): tear the
+        process group down so that neighbours blocked in a receive fail with a transport
+        error instead of waiting for a message that will never come.  (The C++ driver
+        carries a status word in its exchange headers instead, sph_mgpu.h.)"""
+        try:
+            self.dist.destroy_process_group(self.group)
+        except Exception:
+            pass
+
 
 def step_distributed(slab, tr):
     """One step of this rank's slab over a DistTransport: two message rounds (A:
-    particles, B: densities); a third only when a face outgrew its fixed-size message."""
-    slab.local_sort()
-    tr.exchange(*slab.plan_exchange_a())
-    sends, recvs = slab.plan_overflow()
-    if sends or recvs:
-        tr.exchange(sends, recvs)
-    slab.assemble()
-    tr.exchange(*slab.combined_sort_and_density())
-    slab.force()
+    particles, B: densities); a third only when a face outgrew its fixed-size message.
+    A rank whose checks fail raises SphError AFTER closing its end of the transport."""
+    try:
+        slab.local_sort()
+        tr.exchange(*slab.plan_exchange_a())
+        sends, recvs = slab.plan_overflow()
+        if sends or recvs:
+            tr.exchange(sends, recvs)
+        slab.assemble()
+        tr.exchange(*slab.combined_sort_and_density())
+        slab.force()
+    except SphError:
+        tr.abort()
+        raise
 
 
 def nccl_self_copy(dist, group=None):

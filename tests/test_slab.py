@@ -128,6 +128,54 @@ def test_gloo_slabs_equal_single_domain(world, face_cap, tmp_path):
     assert_bit_equal(got[1], want["vel"], "vel")
 
 
+def _gloo_failing_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 3000
+    pos, vel = moving_state(n, 7)
+    settings = sph.default_settings(n, False)
+    p4, v4 = S.pack_state(pos, vel)
+    bounds, parts = S.split_initial(p4, v4, settings.h, 100, world)
+    sl = S.Slab(OracleSlabBackend(settings, n), rank, world, *bounds[rank], 100)
+    sl.load(torch.from_numpy(parts[rank][0]), torch.from_numpy(parts[rank][1]))
+    tr = S.DistTransport(dist, rank, world, torch.device("cpu"))
+    if rank == 0:   # this rank's third step finds its capacity exceeded
+        real = sl.assemble
+        calls = [0]
+
+        def failing():
+            calls[0] += 1
+            if calls[0] == 3:
+                raise S.SphError("slab capacity exceeded by halo + migrants")
+            real()
+        sl.assemble = failing
+    try:
+        for _ in range(6):
+            S.step_distributed(sl, tr)
+        outcome = "finished"
+    except S.SphError as e:
+        outcome = "SphError: " + str(e)
+    except Exception as e:     # the neighbour: its receive fails, it does not hang
+        outcome = "transport: " + type(e).__name__
+    with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+        f.write(outcome)
+
+
+@pytest.mark.timeout(180)
+def test_gloo_failing_rank_does_not_leave_its_neighbour_waiting(tmp_path):
+    """a rank whose capacity / halo check fails must not leave its peers blocked
+    in batch_isend_irecv: it closes its end of the transport before raising."""
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_gloo_failing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "rank0.txt").read_text()
+    r1 = (tmp_path / "rank1.txt").read_text()
+    assert r0.startswith("SphError: slab capacity exceeded")
+    assert r1.startswith("transport: "), r1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,sweep,face_cap", [(2, "list", None), (3, "list", None), (2, "lds", None),
                                                   (3, "lds", None), (3, "list", 300)])
