@@ -28,6 +28,9 @@
 #define RS_SMALL_N (3 << 19)
 #endif
 #define RS_WAVES (RS_THREADS / SPH_WAVE)
+#ifndef RS_HIST_BALLOT
+#define RS_HIST_BALLOT 0 // 1: count with the scatter's ballot match (A/B)
+#endif
 
 // Lanes of this wave whose digit equals mine (among valid lanes).
 template <int BITS>
@@ -93,6 +96,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
         // one digit (already-ordered streams: -i grid, the slab sorts), where the 64-way
         // same-address add would serialise -- then one lane adds the wave's count.
         const uint32_t d = (key >> shift) & (DIG - 1);
+#if RS_HIST_BALLOT
+        unsigned long long mm = match_digit<BITS>(d, valid);
+        if (valid && lanes_below(mm) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(mm));
+#else
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         const unsigned long long live = __ballot(valid);
         if (__ballot(valid && d != d0) == 0ull && (live & 1ull)) {
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
         } else if (valid) {
             atomicAdd(&hist[d], 1u);
         }
+#endif
     }
     __syncthreads();
 #pragma unroll
