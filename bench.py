@@ -107,6 +107,9 @@ def cpu_baseline(n, random_init, steps):
     return out
 
 
+RUNTIME_SETTLE_STEPS = 12   # see main(): untimed, before the W warm-up steps
+
+
 def run_mgpu_bench(args, dist, rank, world, local_rank):
     """N > 1: the C++ in-process driver (libsph_mgpu.so), one process per GPU: each rank
     drives ONE z-slab; the halo layers travel by ncclSend/ncclRecv between the ranks' own
@@ -131,6 +134,10 @@ def run_mgpu_bench(args, dist, rank, world, local_rank):
     mg.setup()
     times = sph.Times()
     # at least one untimed step: the first exchange builds the RCCL channels
+    for _ in range(RUNTIME_SETTLE_STEPS):
+        mg.simulateAndTime(times) if args.mode == "time" else mg.simulate()
+    mg.sync()
+    mg.setup()
     for _ in range(max(args.warmup, 1)):
         mg.simulateAndTime(times) if args.mode == "time" else mg.simulate()
     mg.sync()
@@ -217,6 +224,11 @@ def main():
             sys.exit("bench.py: --gpus N>1 must be launched through torch.distributed.run")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback); use -m 'not gpu' tests on CPU")
+    # torch's lazy device initialisation (context, streams, allocator) happens HERE, not in the
+    # torch.cuda.synchronize() that brackets the timed loop: its deferred work stalled the GPU's
+    # queues for ~7 ms a few hundred microseconds into the loop (scripts/studies)
+    torch.cuda.init()
+    torch.cuda.synchronize()
 
     import cudafluidsimulator_amd as sph
     from cudafluidsimulator_amd import _lib
@@ -247,6 +259,14 @@ def main():
                             key_order=args.key)
         sim.setup()
         times = sph.Times()
+        # Runtime settle, NOT part of W: with torch's bundled HIP runtime loaded, a process's 4th-7th
+        # step meets a one-off ~7 ms stall of the GPU's queues (scripts/studies/early_stall.py; never
+        # with the system runtime ./sph links) -- a fifth of a 20-step run at small n.  Twelve
+        # untimed steps take it out of the way whatever W is; then the W warm-up steps proper.
+        for _ in range(RUNTIME_SETTLE_STEPS):
+            one_step(sim, times)
+        sim.sync()
+        sim.setup()
         for _ in range(W):
             one_step(sim, times)
         sim.sync()
@@ -255,11 +275,17 @@ def main():
         times = sph.Times()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        walls = []
         for _ in range(K):
             one_step(sim, times)
+            walls.append(time.perf_counter())
         sim.sync()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        if os.environ.get("SPH_BENCH_STEP_WALLS"):   # diagnostic: per-step wall times on stderr
+            prev = t0
+            print("step walls (ms): " + " ".join("%.2f" % ((w - p0) * 1e3) for w, p0 in zip(walls, [t0] + walls[:-1])),
+                  file=sys.stderr)
         kt = sim.kernel_times()
         result = dict(elapsed=elapsed, kt=kt, times=times, n_total=n)
         if os.environ.get("SPH_STAMPS"):

@@ -62,6 +62,12 @@ struct sph_handle {
     int2 *cellRange = nullptr;
     float *devPos[2] = {nullptr, nullptr};
     float *hostPos = nullptr; // pinned, n*3
+    // Pinned staging for state uploads (two halves, ping-pong).  A hipMemcpy from pageable
+    // memory makes the runtime pin and later unpin the caller's pages; the unpin is deferred
+    // and stalls the GPU's queues for 6-28 ms some time AFTER the call returned -- inside the
+    // first steps of the run that follows (measured).
+    float4 *stage[2] = {nullptr, nullptr};
+    hipEvent_t stageFree[2] = {nullptr, nullptr};
     bool mappedPos = false;   // SPH_FLAG_MAPPED_POSITIONS: devPos[] alias hostPos (host-mapped)
     // SPH_GRAPH=1: the three phases of a step replayed as hipGraphs (captured once per
     // read-back slot).  Measured (round 2): SLOWER than plain launches -- n = 262,144:
@@ -312,6 +318,19 @@ int alloc_device(sph_handle *h) {
     }
     if (const char *e = getenv("SPH_GRAPH")) h->useGraph = atoi(e) != 0;
     if (h->external) h->useGraph = false; // slab mode: the driver sizes every launch itself
+    // Read-back pre-warm.  The runtime sets up its device-to-host copy path on the first copies
+    // of a process: a one-off ~7 ms stall, which otherwise lands in the first steps of a run
+    // (scripts/studies/early_stall.py).  A few small copies through the same stream and buffers here.
+    if (h->hostPos && h->devPos[0] && !h->mappedPos) {
+        int warm = 16;
+        if (const char *e = getenv("SPH_PREWARM_COPIES")) warm = atoi(e);
+        const size_t bytes = std::min<size_t>(posCap * 3 * sizeof(float), (size_t)1 << 20);
+        for (int k = 0; k < warm; ++k) {
+            HIPCHK(h, hipMemcpyAsync(h->hostPos, h->devPos[k & 1], bytes, hipMemcpyDeviceToHost, h->copy));
+            HIPCHK(h, hipStreamSynchronize(h->copy));
+        }
+        memset(h->hostPos, 0, bytes);
+    }
     HIPCHK(h, hipDeviceSynchronize()); // memsets above ran on the null stream
     return SPH_OK;
 }
@@ -349,6 +368,27 @@ void drop_step_graphs(sph_handle *h) {
     h->graphEvPending[0] = h->graphEvPending[1] = false;
 }
 
+// rows -> device through the handle's pinned staging halves; `fill(k, dst, count)` packs rows
+// [k, k+count) into dst.  Returns when every row is on the device.
+constexpr size_t kStageRows = (size_t)1 << 19; // 8 MB per half
+template <class Fill>
+int staged_upload(sph_handle *h, float4 *dev, size_t n, Fill fill) {
+    for (int b = 0; b < 2; ++b) {
+        if (!h->stage[b]) HIPCHK(h, hipHostMalloc(&h->stage[b], kStageRows * sizeof(float4), hipHostMallocDefault));
+        if (!h->stageFree[b]) HIPCHK(h, hipEventCreateWithFlags(&h->stageFree[b], hipEventDisableTiming));
+    }
+    int b = 0;
+    for (size_t k = 0; k < n; k += kStageRows, b ^= 1) {
+        const size_t cnt = n - k < kStageRows ? n - k : kStageRows;
+        HIPCHK(h, hipEventSynchronize(h->stageFree[b])); // (a never-recorded event is complete)
+        fill(k, h->stage[b], cnt);
+        HIPCHK(h, hipMemcpyAsync(dev + k, h->stage[b], cnt * sizeof(float4), hipMemcpyHostToDevice, h->compute));
+        HIPCHK(h, hipEventRecord(h->stageFree[b], h->compute));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->compute));
+    return SPH_OK;
+}
+
 int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
@@ -376,10 +416,12 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     HIPCHK(h, hipStreamSynchronize(h->copy));
     h->cur = 0;
     if (n > 0) {
-        HIPCHK(h, hipMemcpy(h->pos4[0], p4.data(), (size_t)n * sizeof(float4),
-                            hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->vel4[0], v4.data(), (size_t)n * sizeof(float4),
-                            hipMemcpyHostToDevice));
+        int rc = staged_upload(h, h->pos4[0], (size_t)n,
+                               [&](size_t k, float4 *dst, size_t cnt) { memcpy(dst, p4.data() + k, cnt * sizeof(float4)); });
+        if (!rc)
+            rc = staged_upload(h, h->vel4[0], (size_t)n,
+                               [&](size_t k, float4 *dst, size_t cnt) { memcpy(dst, v4.data() + k, cnt * sizeof(float4)); });
+        if (rc) return rc;
     }
     HIPCHK(h, hipDeviceSynchronize());
     h->zLayers = zmax >= zmin ? zmax - zmin + 1 : 0;
@@ -862,6 +904,10 @@ void sph_destroy(sph_handle *h) {
     if (h->ws.digitTotal) (void)hipFree(h->ws.digitTotal);
     if (h->cellRange) (void)hipFree(h->cellRange);
     if (h->hostPos) (void)hipHostFree(h->hostPos);
+    for (int b = 0; b < 2; ++b) {
+        if (h->stage[b]) (void)hipHostFree(h->stage[b]);
+        if (h->stageFree[b]) (void)hipEventDestroy(h->stageFree[b]);
+    }
     if (h->force4) (void)hipFree(h->force4);
     if (h->pairCounter) (void)hipFree(h->pairCounter);
     if (h->pairHost) (void)hipHostFree(h->pairHost);
@@ -1251,8 +1297,12 @@ int sph_load_state(sph_handle *h, const char *path) {
     HIPCHK(h, hipStreamSynchronize(h->copy));
     h->cur = 0;
     if (n) {
-        HIPCHK(h, hipMemcpy(h->pos4[0], p4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->vel4[0], v4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        int rc = staged_upload(h, h->pos4[0], (size_t)n,
+                               [&](size_t k, float4 *dst, size_t cnt) { memcpy(dst, p4.data() + k, cnt * sizeof(float4)); });
+        if (!rc)
+            rc = staged_upload(h, h->vel4[0], (size_t)n,
+                               [&](size_t k, float4 *dst, size_t cnt) { memcpy(dst, v4.data() + k, cnt * sizeof(float4)); });
+        if (rc) return rc;
     }
     HIPCHK(h, hipDeviceSynchronize());
     drop_step_graphs(h);
@@ -1375,7 +1425,10 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     *out = h->kt;
     if (reset) {
         h->kt = SphKernelTimes{};
-        HIPCHK(h, hipMemset(h->pairCounter, 0, kCounterWords * sizeof(unsigned long long)));
+        // (not hipMemset: the first use of the null stream makes the runtime create another
+        // hardware queue, and that stalled the GPU's queues for ~7 ms a step or two later)
+        HIPCHK(h, hipMemsetAsync(h->pairCounter, 0, kCounterWords * sizeof(unsigned long long), h->compute));
+        HIPCHK(h, hipStreamSynchronize(h->compute));
     }
     return SPH_OK;
 }
