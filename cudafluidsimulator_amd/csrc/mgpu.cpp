@@ -455,8 +455,15 @@ int distribute(sph_mgpu *m, const std::vector<F4> &p4, const std::vector<F4> &v4
         HIPM(m, hipStreamSynchronize(sl.s));
         HIPM(m, hipStreamSynchronize(sl.copy));
         if (!sp.empty()) {
-            HIPM(m, hipMemcpy(sl.pos[0], sp.data(), sp.size() * sizeof(F4), hipMemcpyHostToDevice));
-            HIPM(m, hipMemcpy(sl.vel[0], sv.data(), sv.size() * sizeof(F4), hipMemcpyHostToDevice));
+            // through the slab's pinned read-back buffer (cap rows): a hipMemcpy from pageable
+            // memory leaves a deferred unpin behind that stalls the first steps
+            const size_t bytes = sp.size() * sizeof(F4);
+            memcpy(sl.hostRows, sp.data(), bytes);
+            HIPM(m, hipMemcpyAsync(sl.pos[0], sl.hostRows, bytes, hipMemcpyHostToDevice, sl.s));
+            HIPM(m, hipStreamSynchronize(sl.s));
+            memcpy(sl.hostRows, sv.data(), bytes);
+            HIPM(m, hipMemcpyAsync(sl.vel[0], sl.hostRows, bytes, hipMemcpyHostToDevice, sl.s));
+            HIPM(m, hipStreamSynchronize(sl.s));
         }
         sl.cur = 0;
         sl.off = 0;
