@@ -20,7 +20,9 @@
 // Keys per thread: 16 (4096-key tiles) at large n, 4 (1024-key tiles) below RS_SMALL_N keys,
 // where a launch of 4096-key tiles leaves most of the 256 CUs idle and the per-thread loop of
 // 16 ballot rounds IS the kernel's latency (n = 262,144: 64 tiles).
+#ifndef RS_ITEMS_BIG
 #define RS_ITEMS_BIG 16
+#endif
 #define RS_ITEMS_SMALL 4
 #ifdef RS_SMALL_N_OVERRIDE
 #define RS_SMALL_N RS_SMALL_N_OVERRIDE
