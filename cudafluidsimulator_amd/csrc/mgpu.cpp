@@ -66,6 +66,8 @@ struct Slab {
     hipStream_t copy = nullptr;   // position read-back
     hipEvent_t evDensity = nullptr, evB = nullptr, evBnd = nullptr, evForce = nullptr, evCopy = nullptr;
     hipEvent_t evT[3] = {nullptr, nullptr, nullptr}; // step start, grid done, force done
+    hipEvent_t evTx[2] = {nullptr, nullptr};         // STREAMS transport: [compute, exchange] stream reached its sends
+    hipEvent_t evRx[2] = {nullptr, nullptr};         //                    ... its receives have landed
     F4 *pos[2] = {nullptr, nullptr}, *vel[2] = {nullptr, nullptr};
     F4 *rx_pos[2] = {nullptr, nullptr}, *rx_vel[2] = {nullptr, nullptr}; // [0] from below, [1] from above
     F4 *ex_pos[2] = {nullptr, nullptr}, *ex_vel[2] = {nullptr, nullptr}; // overflow messages (rare)
@@ -270,6 +272,36 @@ int deliver(sph_mgpu *m, const std::vector<Msg> &msgs, bool on_comm_stream) {
         }
         return SPH_OK;
     }
+    if (tr == SPH_TRANSPORT_STREAMS) {
+        // what a grouped ncclSend/ncclRecv round does to the participating streams, with copies:
+        // a receive starts once the sender's stream has reached the round, and no stream of the
+        // round goes on before the messages it sends and receives are through
+        const int q = on_comm_stream ? 1 : 0;
+        auto stream_of = [&](Slab *sl) { return on_comm_stream ? sl->comm : sl->s; };
+        std::vector<Slab *> part;
+        for (const Msg &g : msgs) {
+            if (!g.src || !g.dst) return fail(m, SPH_ESTATE, "streams transport needs every slab in this process");
+            if (!g.bytes) continue;
+            for (int r : {g.src_rank, g.dst_rank}) {
+                Slab *sl = local(m, r);
+                if (std::find(part.begin(), part.end(), sl) == part.end()) part.push_back(sl);
+            }
+        }
+        for (Slab *sl : part) HIPM(m, hipEventRecord(sl->evTx[q], stream_of(sl)));
+        for (const Msg &g : msgs) {
+            if (!g.bytes) continue;
+            Slab *a = local(m, g.src_rank), *b = local(m, g.dst_rank);
+            HIPM(m, hipStreamWaitEvent(stream_of(b), a->evTx[q], 0));
+            HIPM(m, hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyDeviceToDevice, stream_of(b)));
+        }
+        for (Slab *sl : part) HIPM(m, hipEventRecord(sl->evRx[q], stream_of(sl)));
+        for (const Msg &g : msgs) {
+            if (!g.bytes) continue;
+            Slab *a = local(m, g.src_rank), *b = local(m, g.dst_rank);
+            HIPM(m, hipStreamWaitEvent(stream_of(a), b->evRx[q], 0)); // the sender's buffer is free again
+        }
+        return SPH_OK;
+    }
     if (tr == SPH_TRANSPORT_LOOPBACK) {
         for (const Msg &g : msgs) {
             if (!g.src || !g.dst) return fail(m, SPH_ESTATE, "loopback transport needs every slab in this process");
@@ -341,7 +373,8 @@ int free_slab(Slab &sl) {
     if (sl.sortb) (void)hipFree(sl.sortb);
     if (sl.pinned) (void)hipHostFree(sl.pinned);
     if (sl.hostRows) (void)hipHostFree(sl.hostRows);
-    for (hipEvent_t e : {sl.evDensity, sl.evB, sl.evBnd, sl.evForce, sl.evCopy, sl.evT[0], sl.evT[1], sl.evT[2]})
+    for (hipEvent_t e : {sl.evDensity, sl.evB, sl.evBnd, sl.evForce, sl.evCopy, sl.evT[0], sl.evT[1], sl.evT[2],
+                         sl.evTx[0], sl.evTx[1], sl.evRx[0], sl.evRx[1]})
         if (e) (void)hipEventDestroy(e);
     if (sl.comm) (void)hipStreamDestroy(sl.comm);
     if (sl.bnd) (void)hipStreamDestroy(sl.bnd);
@@ -380,7 +413,8 @@ int alloc_slab(sph_mgpu *m, Slab &sl) {
     HIPM(m, hipHostMalloc(&sl.pinned, 32 * sizeof(int), hipHostMallocDefault));
     memset(sl.pinned, 0, 32 * sizeof(int));
     HIPM(m, hipHostMalloc(&sl.hostRows, rows * sizeof(F4), hipHostMallocDefault));
-    for (hipEvent_t *e : {&sl.evDensity, &sl.evB, &sl.evBnd, &sl.evForce, &sl.evCopy})
+    for (hipEvent_t *e : {&sl.evDensity, &sl.evB, &sl.evBnd, &sl.evForce, &sl.evCopy, &sl.evTx[0], &sl.evTx[1],
+                          &sl.evRx[0], &sl.evRx[1]})
         HIPM(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (auto &e : sl.evT) HIPM(m, hipEventCreate(&e));
     HIPM(m, hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
@@ -555,9 +589,10 @@ int sph_mgpu_create(const SphSettings *settings, const SphMgpuOptions *options, 
     if (o.world < 1 || o.rank_count < 1 || o.rank_count > SPH_MGPU_MAX_LOCAL || o.rank_begin < 0 ||
         o.rank_begin + o.rank_count > o.world)
         return fail(nullptr, SPH_EINVAL, "bad world / rank range");
-    if (o.transport < SPH_TRANSPORT_LOOPBACK || o.transport > SPH_TRANSPORT_MAILBOX)
+    if (o.transport < SPH_TRANSPORT_LOOPBACK || o.transport > SPH_TRANSPORT_STREAMS)
         return fail(nullptr, SPH_EINVAL, "unknown transport");
-    if ((o.transport == SPH_TRANSPORT_LOOPBACK || o.transport == SPH_TRANSPORT_RCCL_SELF) && o.rank_count != o.world)
+    if ((o.transport == SPH_TRANSPORT_LOOPBACK || o.transport == SPH_TRANSPORT_RCCL_SELF ||
+         o.transport == SPH_TRANSPORT_STREAMS) && o.rank_count != o.world)
         return fail(nullptr, SPH_EINVAL, "loopback / self transports need every slab in this process");
     if (o.transport == SPH_TRANSPORT_MAILBOX && o.rank_count != 1)
         return fail(nullptr, SPH_EINVAL, "mailbox transport: one slab per driver object");
@@ -575,11 +610,11 @@ int sph_mgpu_create(const SphSettings *settings, const SphMgpuOptions *options, 
     m->n = settings->numParticles;
     m->D = (int)settings->numCellsPerDim;
     m->DD = m->D * m->D;
-    m->shared_stream = o.transport != SPH_TRANSPORT_RCCL;
+    m->shared_stream = o.transport != SPH_TRANSPORT_RCCL && o.transport != SPH_TRANSPORT_STREAMS;
     m->slabs.resize(o.rank_count);
     for (int k = 0; k < o.rank_count; ++k) {
         m->slabs[k].rank = o.rank_begin + k;
-        m->slabs[k].device = m->shared_stream ? o.devices[0] : o.devices[k];
+        m->slabs[k].device = o.transport == SPH_TRANSPORT_RCCL ? o.devices[k] : o.devices[0];
         if (m->slabs[k].device < 0 || m->slabs[k].device >= ndev) {
             delete m;
             return fail(nullptr, SPH_EINVAL, "device ordinal out of range");

@@ -79,6 +79,7 @@ void Simulator::setup() {
         const char *tr = getenv("SPH_TRANSPORT");
         mo.transport = (tr && strcmp(tr, "loopback") == 0) ? SPH_TRANSPORT_LOOPBACK
                        : (tr && strcmp(tr, "rccl_self") == 0) ? SPH_TRANSPORT_RCCL_SELF
+                       : (tr && strcmp(tr, "streams") == 0)   ? SPH_TRANSPORT_STREAMS
                                                                : SPH_TRANSPORT_RCCL;
         for (int k = 0; k < SPH_MGPU_MAX_LOCAL; ++k) mo.devices[k] = mo.transport == SPH_TRANSPORT_RCCL ? k : 0;
         mo.sweep = o.sweep;

@@ -19,7 +19,7 @@ from ._lib import SphError, SphSettings, SphTimes, load_library
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_LOCAL = 8
-TRANSPORTS = {"loopback": 0, "rccl": 1, "rccl_self": 2, "mailbox": 3}
+TRANSPORTS = {"loopback": 0, "rccl": 1, "rccl_self": 2, "mailbox": 3, "streams": 4}
 
 # every symbol include/sph_mgpu.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [

@@ -45,11 +45,18 @@ enum {
     SPH_TRANSPORT_LOOPBACK = 0,  /* device-to-device copies; every slab on devices[0] */
     SPH_TRANSPORT_RCCL = 1,      /* ncclSend/ncclRecv between the slabs' GPUs */
     SPH_TRANSPORT_RCCL_SELF = 2, /* one-rank communicator, every message sent to itself */
-    SPH_TRANSPORT_MAILBOX = 3    /* TEST HOOK for the one-process-per-GPU code path on a one-GPU box:
+    SPH_TRANSPORT_MAILBOX = 3,   /* TEST HOOK for the one-process-per-GPU code path on a one-GPU box:
                                     `world` driver objects of one slab each live in ONE process on one
                                     device and stand for the ranks; a message is a note in a process-wide
                                     table.  Every object must be stepped phase by phase
                                     (sph_mgpu_step_phase 1..4 on all ranks before the next phase). */
+    SPH_TRANSPORT_STREAMS = 4    /* the RCCL transport's stream layout on ONE device: every slab has its
+                                    own compute, exchange and boundary streams, exchange B overlaps the
+                                    interior force sweep, the boundary layers run on a stream of their
+                                    own -- and a message is a device-to-device copy ordered by events the
+                                    way a grouped ncclSend/ncclRecv orders it (receiver after the
+                                    sender's stream reached the send, sender held until the copy is done).
+                                    Exercises everything of the RCCL path but RCCL itself on a one-GPU box. */
 };
 
 typedef struct SphMgpuOptions {

@@ -67,8 +67,11 @@ def single_domain(settings, pos, vel, steps, sweep="list"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,transport", [(2, "loopback"), (4, "loopback"), (8, "loopback"), (3, "rccl_self")])
+@pytest.mark.parametrize("world,transport", [(2, "loopback"), (4, "loopback"), (8, "loopback"), (3, "rccl_self"),
+                                             (2, "streams"), (5, "streams"), (8, "streams")])
 def test_slabs_equal_single_domain(world, transport):
+    """"streams": the RCCL transport's stream layout (per-slab compute / exchange / boundary
+    streams, exchange B beside the interior force sweep) with event-ordered copies as messages."""
     n, steps = 80000, 8
     pos, vel = moving_state(n, 5)
     settings = sph.default_settings(n, False)
@@ -90,7 +93,8 @@ def test_slabs_equal_single_domain(world, transport):
 
 
 @pytest.mark.gpu
-def test_two_layer_hops_and_tiny_faces():
+@pytest.mark.parametrize("transport", ["loopback", "streams"])
+def test_two_layer_hops_and_tiny_faces(transport):
     """z-velocities up to 2.5 cells per step: migrants land beyond the neighbour's first
     layer (the headers carry the near/far split); faces far too small for the traffic, so
     the exact-size second round carries most of it."""
@@ -98,7 +102,7 @@ def test_two_layer_hops_and_tiny_faces():
     pos, vel = moving_state(n, 11, vz=25.0)
     settings = sph.default_settings(n, False)
     want, _ = single_domain(settings, pos, vel, steps)
-    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback", face_capacity=300)
+    mg = M.MultiGpuSimulator(settings, world=world, transport=transport, face_capacity=300)
     mg.upload_state(pos, vel)
     for _ in range(steps):
         mg.simulate()
@@ -128,14 +132,14 @@ def test_hop_beyond_a_whole_slab_is_reported():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep", ["list", "lds"])
-def test_reference_initialiser_and_recut(sweep):
+@pytest.mark.parametrize("sweep,transport", [("list", "loopback"), ("lds", "loopback"), ("list", "streams")])
+def test_reference_initialiser_and_recut(sweep, transport):
     """-i random through 4 slabs with the cuts re-balanced every 3 steps (a re-cut is a
     stable filter of the rank-concatenated sequence, so it keeps the canonical order)."""
     n, steps, world = 262144, 7, 4
     settings = sph.default_settings(n, True)
     want, _ = single_domain(settings, None, None, steps, sweep=sweep)
-    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback", sweep=sweep, recut_every=3)
+    mg = M.MultiGpuSimulator(settings, world=world, transport=transport, sweep=sweep, recut_every=3)
     mg.setup()
     t = sph.Times()
     for _ in range(steps):
