@@ -133,3 +133,20 @@ def test_config5_67108864_eight_slabs_equal_single_domain():
     assert (want["rho"] > 1000).sum() > n // 4
     assert_bit_equal(got["pos"], want["pos"], "67M dense lattice, 8 slabs vs single domain: pos")
     assert_bit_equal(got["rho"], want["rho"], "67M dense lattice, 8 slabs vs single domain: rho")
+
+
+def test_headline_config_beyond_the_goldens_list_equals_lds():
+    """Past the 100 steps the goldens cover the fluid keeps piling up on the floor (hundreds of
+    particles per cell, rho several times the rest density): runs far longer than the LDS slice,
+    the largest hit-stream reservations.  Two kernel families must still agree bit for bit."""
+    n, steps = 4194304, 150
+    a = run(n, steps, "list")
+    sa = a.download_state()
+    g = a.download_grid()
+    assert (g["cells"][:, 1] - g["cells"][:, 0]).max() > 150
+    a.close()
+    b = run(n, steps, "lds")
+    sb = b.download_state()
+    b.close()
+    for k in ("pos", "vel", "rho"):
+        assert_bit_equal(sa[k], sb[k], k + " @ step 150")
