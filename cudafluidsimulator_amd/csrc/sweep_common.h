@@ -85,6 +85,43 @@ struct ForceAcc {
     float fx, fy, fz;
 };
 
+// ---- correctly rounded divide and square root without the range fix-ups ----
+// hipcc expands `a / b` to v_div_scale x2, v_rcp, a Newton chain of five fmas, v_div_fmas and
+// v_div_fixup (11 instructions), and sqrtf() to a scaled v_sqrt with two one-ulp corrections and
+// a class check (17).  The scale / fix-up instructions only act on operands near the ends of the
+// exponent range, on denormals, infinities and NaNs; the pair body's operands are nowhere near
+// (densities 30..1e5, distances 1e-4..0.1, numerators 0 or 1e-10..1e7), so the bare Newton
+// chain -- the same fmas in the same order -- returns the same correctly rounded bits.  The
+// two divisions by rho_j share the refined reciprocal (x / (2 rho) == (x / rho) / 2 exactly).
+// SW_SLIM_DIV=0 restores the compiler's expansions (A/B, and the check that nothing changes).
+#ifndef SW_SLIM_DIV
+#define SW_SLIM_DIV 1
+#endif
+__device__ __forceinline__ float sw_recip_refined(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e0, r0, r0);
+}
+__device__ __forceinline__ float sw_div_with(float a, float b, float r1) { // a / b, r1 = sw_recip_refined(b)
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+// sqrtf(x) for x = 0 or x >= 2^-96 (a smaller x gives some value far below SPH_EPS_F, which is
+// all the callers' `dist < SPH_EPS_F` gate needs)
+__device__ __forceinline__ float sw_sqrt(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1);
+    const float sp = __int_as_float(__float_as_int(s) + 1);
+    const float tm = __builtin_fmaf(-sm, s, x);
+    const float tp = __builtin_fmaf(-sp, s, x);
+    float r = (0.f >= tm) ? sm : s;
+    r = (0.f < tp) ? sp : r;
+    return r;
+}
+
 // One neighbour of kernelUpdateForces (simulator.cu:223-251) with
 // pressureKernel (:99-117) and viscosityKernel (:119-130) inlined.
 __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float piy,
@@ -97,6 +134,36 @@ __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float 
     float dist2 = dx * dx + dy * dy + dz * dz;
     float rho_j = vj.w;
     float prs_j = fmaxf(0.f, SPH_GAS_CONSTANT * (rho_j - SPH_REST_DENSITY));
+#if SW_SLIM_DIV
+    float dist = sw_sqrt(dist2);
+    bool tiny = dist < SPH_EPS_F;
+    const bool inP = !(dist2 > P.h2) && !tiny, inV = !(dist > P.h) && !tiny;
+    float rrho = 0.f;
+    if (inP || inV) rrho = sw_recip_refined(rho_j);
+    if (inP) {
+        // x / (2 rho) = (x / rho) / 2: the halving is exact
+        float fPressure = 0.5f * sw_div_with(-SPH_MASS * (prs_i + prs_j), rho_j, rrho);
+        const float sn = (-P.vcoef) * (P.h - dist) * (P.h - dist);
+        float scale = sw_div_with(sn, dist, sw_recip_refined(dist));
+        float kx = dx * scale, ky = dy * scale, kz = dz * scale;
+        kx *= fPressure;
+        ky *= fPressure;
+        kz *= fPressure;
+        F.fx += kx;
+        F.fy += ky;
+        F.fz += kz;
+    }
+    if (inV) {
+        float fViscosity = sw_div_with(SPH_VISCOSITY * SPH_MASS * (P.vcoef * (P.h - dist)), rho_j, rrho);
+        float dvx = vj.x - vix, dvy = vj.y - viy, dvz = vj.z - viz;
+        dvx *= fViscosity;
+        dvy *= fViscosity;
+        dvz *= fViscosity;
+        F.fx += dvx;
+        F.fy += dvy;
+        F.fz += dvz;
+    }
+#else
     float dist = sqrtf(dist2);
     bool tiny = dist < SPH_EPS_F;
     if (!(dist2 > P.h2) && !tiny) {
@@ -121,6 +188,7 @@ __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float 
         F.fy += dvy;
         F.fz += dvz;
     }
+#endif
 }
 
 // ---- SPH_MATH_FAST variants: same formulas, FMA-contracted, with the hardware's

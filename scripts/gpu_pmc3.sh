@@ -11,5 +11,5 @@ for ctrs in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_
   echo "pass $i ($ctrs) exit $?"
 done
 cd $GRAFT_REPO_ROOT
-python3 scripts/pmc_summary.py $OUT > $OUT/pmc_summary.csv; grep -E "density|force" $OUT/pmc_summary.csv
+python3 scripts/pmc_summary.py $OUT ${PMC_STEPS:-10} > $OUT/pmc_summary.csv; grep -E "density|force" $OUT/pmc_summary.csv
 find $OUT -name "*counter_collection.csv" -size +4M -delete

@@ -12,5 +12,5 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
   echo "pass $i exit $?"
 done
 cd $GRAFT_REPO_ROOT
-python3 scripts/pmc_summary.py $OUT > $OUT/pmc_summary.csv; grep -i "force_list\|density_mask" $OUT/pmc_summary.csv
+python3 scripts/pmc_summary.py $OUT ${PMC_STEPS:-20} > $OUT/pmc_summary.csv; grep -i "force_list\|density_mask" $OUT/pmc_summary.csv
 find $OUT -name "*counter_collection.csv" -size +4M -delete
