@@ -97,6 +97,9 @@ struct ForceAcc {
 #ifndef SW_SLIM_DIV
 #define SW_SLIM_DIV 1
 #endif
+#ifndef SW_BRANCHFREE
+#define SW_BRANCHFREE 1
+#endif
 __device__ __forceinline__ float sw_recip_refined(float b) {
     const float r0 = __builtin_amdgcn_rcpf(b);
     const float e0 = __builtin_fmaf(-b, r0, 1.0f);
@@ -134,7 +137,34 @@ __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float 
     float dist2 = dx * dx + dy * dy + dz * dz;
     float rho_j = vj.w;
     float prs_j = fmaxf(0.f, SPH_GAS_CONSTANT * (rho_j - SPH_REST_DENSITY));
-#if SW_SLIM_DIV
+#if SW_SLIM_DIV && SW_BRANCHFREE
+    // One basic block: the three Newton chains and the square root's corrections interleave, the
+    // gates become selects.  Adding +0 for a gated-out term is exact: F starts at +0 and an IEEE
+    // sum is -0 only if both operands are.  A coincident pair (dist = 0) makes NaNs that the
+    // selects discard.
+    const float dist = sw_sqrt(dist2);
+    const bool tiny = dist < SPH_EPS_F;
+    const bool inP = !(dist2 > P.h2) && !tiny, inV = !(dist > P.h) && !tiny;
+    const float rrho = sw_recip_refined(rho_j);
+    const float hd = P.h - dist;
+    const float fPressure = 0.5f * sw_div_with(-SPH_MASS * (prs_i + prs_j), rho_j, rrho);
+    const float scale = sw_div_with((-P.vcoef) * hd * hd, dist, sw_recip_refined(dist));
+    const float fViscosity = sw_div_with(SPH_VISCOSITY * SPH_MASS * (P.vcoef * hd), rho_j, rrho);
+    float kx = dx * scale, ky = dy * scale, kz = dz * scale;
+    kx *= fPressure;
+    ky *= fPressure;
+    kz *= fPressure;
+    float dvx = vj.x - vix, dvy = vj.y - viy, dvz = vj.z - viz;
+    dvx *= fViscosity;
+    dvy *= fViscosity;
+    dvz *= fViscosity;
+    F.fx += inP ? kx : 0.f;
+    F.fy += inP ? ky : 0.f;
+    F.fz += inP ? kz : 0.f;
+    F.fx += inV ? dvx : 0.f;
+    F.fy += inV ? dvy : 0.f;
+    F.fz += inV ? dvz : 0.f;
+#elif SW_SLIM_DIV
     float dist = sw_sqrt(dist2);
     bool tiny = dist < SPH_EPS_F;
     const bool inP = !(dist2 > P.h2) && !tiny, inV = !(dist > P.h) && !tiny;
