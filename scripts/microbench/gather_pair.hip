@@ -19,11 +19,27 @@ __device__ __forceinline__ unsigned lcg(unsigned &s) {
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k(const float4 *__restrict__ tab, float *__restrict__ out, int nrec, int HOOD) {
+    __shared__ float pad_lds[1536]; // 6 KB per one-wave workgroup: the same 26 waves per CU in every mode
     const int lane = threadIdx.x, wave = blockIdx.x;
+    if (HOOD < 0) pad_lds[lane] = 1.f;
     const int base = min(max(wave * 64 - HOOD / 2, 0), nrec - HOOD);
     unsigned s = wave * 64u + lane + 12345u;
     float acc = 0.f;
-    if (MODE == 2) { // position half only: one gather per trip
+    if (MODE == 3) { // the record as four 8-byte loads
+        const float2 *tab2 = reinterpret_cast<const float2 *>(tab);
+        int j0 = base + lcg(s) % HOOD, j1 = base + lcg(s) % HOOD;
+        float2 a0 = tab2[4 * (size_t)j0], b0 = tab2[4 * (size_t)j0 + 1], c0 = tab2[4 * (size_t)j0 + 2], d0 = tab2[4 * (size_t)j0 + 3];
+        float2 a1 = tab2[4 * (size_t)j1], b1 = tab2[4 * (size_t)j1 + 1], c1 = tab2[4 * (size_t)j1 + 2], d1 = tab2[4 * (size_t)j1 + 3];
+        for (int t = 0; t < TRIPS; t += 2) {
+            acc += a0.x * c0.y + b0.x * d0.y;
+            j0 = base + lcg(s) % HOOD;
+            a0 = tab2[4 * (size_t)j0]; b0 = tab2[4 * (size_t)j0 + 1]; c0 = tab2[4 * (size_t)j0 + 2]; d0 = tab2[4 * (size_t)j0 + 3];
+            acc += a1.x * c1.y + b1.x * d1.y;
+            j1 = base + lcg(s) % HOOD;
+            a1 = tab2[4 * (size_t)j1]; b1 = tab2[4 * (size_t)j1 + 1]; c1 = tab2[4 * (size_t)j1 + 2]; d1 = tab2[4 * (size_t)j1 + 3];
+        }
+        acc += a0.x + c0.x + a1.x + c1.x;
+    } else if (MODE == 2) { // position half only: one gather per trip
         int j0 = base + lcg(s) % HOOD, j1 = base + lcg(s) % HOOD;
         float4 p0 = tab[2 * (size_t)j0], p1 = tab[2 * (size_t)j1];
         for (int t = 0; t < TRIPS; t += 2) {
@@ -107,14 +123,15 @@ int main() {
     std::vector<float> r0((size_t)waves * 64), r1((size_t)waves * 64);
     // neighbourhood sizes: 64 records = 2 KB (L1-resident), 2,304 = 74 KB (the force sweep's), 65,536 = 2 MB (L2 only)
     for (int hood : {64, 512, 2304, 65536}) {
-        float ms[3];
-        for (int mode = 0; mode < 3; ++mode) {
+        float ms[4];
+        for (int mode = 0; mode < 4; ++mode) {
             for (int rep = 0; rep < 2; ++rep) { // second timing counts
                 (void)hipEventRecord(e0);
                 for (int q = 0; q < 5; ++q) {
                     if (mode == 0) k<0><<<waves, 64>>>(tab, out, nrec, hood);
                     else if (mode == 1) k<1><<<waves, 64>>>(tab, out, nrec, hood);
-                    else k<2><<<waves, 64>>>(tab, out, nrec, hood);
+                    else if (mode == 2) k<2><<<waves, 64>>>(tab, out, nrec, hood);
+                    else k<3><<<waves, 64>>>(tab, out, nrec, hood);
                 }
                 (void)hipEventRecord(e1);
                 (void)hipEventSynchronize(e1);
@@ -125,7 +142,7 @@ int main() {
         size_t bad = 0;
         for (size_t i = 0; i < r0.size(); ++i) bad += r0[i] != r1[i];
         printf("neighbourhood %6d records: own-record gathers %.3f ms/launch | lane-pair gathers %.3f (results differ in %zu lanes) | "
-               "position half only %.3f\n", hood, ms[0] / 5, ms[1] / 5, bad, ms[2] / 5);
+               "position half only %.3f | four 8-byte loads %.3f\n", hood, ms[0] / 5, ms[1] / 5, bad, ms[2] / 5, ms[3] / 5);
     }
     return 0;
 }
