@@ -6,6 +6,7 @@ path and the oracle to each other across rounds, not to the reference.  Data
 only: inputs are regenerated from seeds / the reference initialisers.
 Run:  python tests/golden/make_golden.py          (the small array fixtures)
       python tests/golden/make_golden.py --full   (sha256 of the n = 4,194,304 run)
+      python tests/golden/make_golden.py --config4 | --config5   (first steps of configs 4 / 5 at full size)
 """
 import os
 import sys
@@ -86,7 +87,37 @@ def full_size_checksums(n=4194304, checkpoints=(1, 10, 30, 50, 60, 80, 100), dum
     with open(os.path.join(HERE, f"random{n}_sha256.json"), "w") as f:
         json.dump(out, f, indent=1)
 
+def big_config_checksums(n, random_init, checkpoints):
+    """BASELINE configs 4 (-n 16777216 -i random) and 5 (-n 67108864 -i grid, the dense-lattice
+    extension): sha256 of the oracle's arrays after the first step(s) at FULL size.  Config 5 is
+    ~1.3e11 pair tests per sweep: a few CPU-minutes per step."""
+    import hashlib
+    import json
+    sim = O.OracleSim(n, random_init)
+    sim.setup()
+    init = "random" if random_init else "grid"
+    out = {"n": n, "init": init, "order": "particle id", "dtype": "<f4", "steps": {}}
+    done = 0
+    for k in checkpoints:
+        sim.step(k - done)
+        done = k
+        d = sim.download()
+        out["steps"][str(k)] = {"pos_sha256": hashlib.sha256(np.ascontiguousarray(d["pos"]).tobytes()).hexdigest(),
+                                "rho_sha256": hashlib.sha256(np.ascontiguousarray(d["rho"]).tobytes()).hexdigest(),
+                                "pair_tests": int(sim.last_pair_tests()), "rho_max": float(d["rho"].max()),
+                                "particles_with_pressure": int((d["rho"] > 1000.0).sum())}
+        print(n, k, out["steps"][str(k)], flush=True)
+    with open(os.path.join(HERE, f"{init}{n}_sha256.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
+    if "--config4" in sys.argv:
+        big_config_checksums(16777216, True, (1, 2))
+        sys.exit(0)
+    if "--config5" in sys.argv:
+        big_config_checksums(67108864, False, (1,))
+        sys.exit(0)
     if "--full" in sys.argv:
         dd = sys.argv[sys.argv.index("--dump-dir") + 1] if "--dump-dir" in sys.argv else None
         full_size_checksums(dump_dir=dd)

@@ -150,3 +150,51 @@ def test_headline_config_beyond_the_goldens_list_equals_lds():
     b.close()
     for k in ("pos", "vel", "rho"):
         assert_bit_equal(sa[k], sb[k], k + " @ step 150")
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _golden(name):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    if not os.path.exists(path):
+        pytest.skip(name + " not generated (tests/golden/make_golden.py)")
+    return json.load(open(path))
+
+
+def test_config4_16777216_matches_the_oracles_checksums():
+    """BASELINE configs[3] at full size against the ORACLE (sha256 of its arrays after steps 1
+    and 2, tests/golden/make_golden.py --config4): 32.8 particles per cell, 21 k particles
+    with pressure on in the very first step."""
+    g = _golden("random16777216_sha256.json")
+    n = g["n"]
+    sim = sph.Simulator(sph.default_settings(n, True))
+    sim.setup()
+    done = 0
+    for k in sorted(int(x) for x in g["steps"]):
+        for _ in range(k - done):
+            sim.simulate()
+        done = k
+        st = sim.download_state()
+        assert _sha(st["pos"]) == g["steps"][str(k)]["pos_sha256"], f"pos @ step {k}"
+        assert _sha(st["rho"]) == g["steps"][str(k)]["rho_sha256"], f"rho @ step {k}"
+    sim.close()
+
+
+def test_config5_67108864_matches_the_oracles_checksum():
+    """BASELINE configs[4] (the dense-lattice extension) at full size against the ORACLE: sha256
+    of its position and density arrays after the first step (71 particles per cell, 1.3e11 pair
+    tests per sweep, pressure on everywhere; tests/golden/make_golden.py --config5)."""
+    g = _golden("grid67108864_sha256.json")
+    n = g["n"]
+    sim = sph.Simulator(sph.default_settings(n, False))
+    sim.setup()
+    sim.simulate()
+    st = sim.download_state()
+    assert _sha(st["pos"]) == g["steps"]["1"]["pos_sha256"], "pos @ step 1"
+    assert _sha(st["rho"]) == g["steps"]["1"]["rho_sha256"], "rho @ step 1"
+    sim.close()
