@@ -28,9 +28,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -89,6 +93,23 @@ struct Slab {
     int status = 0;
 };
 
+// Optional host threads, one per local slab (SPH_MGPU_THREADS=1): the ~25 launches of a slab step
+// cost the ONE host thread ~0.13 ms per slab, so an in-process run of eight GPUs is bound by the
+// host at this problem size (profiles/r02_experiments.md).  The per-slab parts of a step (partition;
+// assemble + sort + density; force + read-back) touch one slab each and run on the slab's worker;
+// everything that spans slabs (message rounds, the host synchronisation, re-cuts) stays on the
+// calling thread, between two joins.  Off by default: one host thread, as the reference has.
+struct Workers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable wake, done;
+    const std::function<int(int)> *job = nullptr; // slab index -> status
+    long long generation = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+};
+
 } // namespace
 
 struct sph_mgpu {
@@ -110,14 +131,87 @@ struct sph_mgpu {
     std::chrono::steady_clock::time_point t_begin;
     bool overflow = false;
     int phase = 0;                 // phases of the current step already done (0..3)
+    std::mutex errMu;              // fail() from worker threads
+    Workers *workers = nullptr;    // SPH_MGPU_THREADS=1
 };
 
 namespace {
 
 int fail(sph_mgpu *m, int code, const std::string &msg) {
-    if (m) m->err = msg;
-    else g_create_error = msg;
+    if (m) {
+        std::lock_guard<std::mutex> lk(m->errMu);
+        m->err = msg;
+    } else {
+        g_create_error = msg;
+    }
     return code;
+}
+
+// Run fn(slab) for every local slab: in rank order on the calling thread, or on the slabs'
+// worker threads (all joined before this returns).  First non-zero status wins.
+int for_each_slab(sph_mgpu *m, const std::function<int(Slab &)> &fn) {
+    Workers *w = m->workers;
+    if (!w) {
+        for (auto &sl : m->slabs) {
+            int rc = fn(sl);
+            if (rc) return rc;
+        }
+        return SPH_OK;
+    }
+    const std::function<int(int)> job = [&](int k) { return fn(m->slabs[k]); };
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->job = &job;
+        w->pending = (int)w->threads.size();
+        std::fill(w->rc.begin(), w->rc.end(), SPH_OK);
+        ++w->generation;
+        w->wake.notify_all();
+        w->done.wait(lk, [&] { return w->pending == 0; });
+        w->job = nullptr;
+    }
+    for (int rc : w->rc)
+        if (rc) return rc;
+    return SPH_OK;
+}
+
+void start_workers(sph_mgpu *m) {
+    Workers *w = new Workers();
+    const int n = (int)m->slabs.size();
+    w->rc.assign(n, SPH_OK);
+    for (int k = 0; k < n; ++k)
+        w->threads.emplace_back([w, k]() {
+            long long seen = 0;
+            for (;;) {
+                const std::function<int(int)> *job;
+                {
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    w->wake.wait(lk, [&] { return w->stop || w->generation != seen; });
+                    if (w->stop) return;
+                    seen = w->generation;
+                    job = w->job;
+                }
+                const int rc = (*job)(k);
+                {
+                    std::lock_guard<std::mutex> lk(w->mu);
+                    w->rc[k] = rc;
+                    if (--w->pending == 0) w->done.notify_all();
+                }
+            }
+        });
+    m->workers = w;
+}
+
+void stop_workers(sph_mgpu *m) {
+    Workers *w = m->workers;
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+        w->wake.notify_all();
+    }
+    for (auto &t : w->threads) t.join();
+    delete w;
+    m->workers = nullptr;
 }
 
 #define HIPM(m, call)                                                                 \
@@ -654,12 +748,15 @@ int sph_mgpu_create(const SphSettings *settings, const SphMgpuOptions *options, 
         sph_mgpu_destroy(m);
         return rc;
     }
+    if (const char *e = getenv("SPH_MGPU_THREADS"))
+        if (atoi(e) != 0 && m->slabs.size() > 1) start_workers(m);
     *out = m;
     return SPH_OK;
 }
 
 void sph_mgpu_destroy(sph_mgpu *m) {
     if (!m) return;
+    stop_workers(m);
     for (auto &sl : m->slabs) {
         (void)hipSetDevice(sl.device);
         if (sl.s) (void)hipStreamSynchronize(sl.s);
@@ -703,7 +800,7 @@ int step_phase1(sph_mgpu *m, SphTimes *times) {
     m->t_begin = std::chrono::steady_clock::now();
 
     // ---- 1. partition the owned rows by the z-range of their NEW cell (no host round trip)
-    for (auto &sl : m->slabs) {
+    int rcl = for_each_slab(m, [&](Slab &sl) -> int {
         HIPM(m, hipSetDevice(sl.device));
         if (times) HIPM(m, hipEventRecord(sl.evT[0], sl.s));
         const uint32_t thr[6] = {(uint32_t)(std::max(sl.zlo - 1, 0) * DD), (uint32_t)(sl.zlo * DD),
@@ -715,7 +812,9 @@ int step_phase1(sph_mgpu *m, SphTimes *times) {
         HIPM(m, hipMemcpyAsync(&sl.hdr_tx->status, &sl.pinned[31], sizeof(int), hipMemcpyHostToDevice, sl.s));
         HIPM(m, hipMemcpyAsync(sl.pinned, sl.hdr_tx, sizeof(Hdr), hipMemcpyDeviceToHost, sl.s));
         sl.sbuf = sl.cur ^ 1;
-    }
+        return SPH_OK;
+    });
+    if (rcl) return rcl;
     // ---- 2. exchange A: header + fixed-size windows, one round
     {
         std::vector<Msg> msgs;
@@ -821,7 +920,7 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
     int rc0 = resolve_mail(m);
     if (rc0) return rc0;
     // ---- 4. assemble, sort, density
-    for (auto &sl : m->slabs) {
+    int rcl = for_each_slab(m, [&](Slab &sl) -> int {
         HIPM(m, hipSetDevice(sl.device));
         const Hdr &me = sl.mine;
         const int m0 = me.b[1], m1 = me.b[2], m2 = me.b[3], m3 = me.b[4], n = me.n;
@@ -889,7 +988,9 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
         if (times) HIPM(m, hipEventRecord(sl.evT[1], sl.s));
         SPHM(m, sl, sph_slab_density(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb));
         if (sl.comm) HIPM(m, hipEventRecord(sl.evDensity, sl.s));
-    }
+        return SPH_OK;
+    });
+    if (rcl) return rcl;
     // ---- 5. exchange B (rho of the boundary layers, rides in vel4.w) || interior force sweep
     {
         std::vector<Msg> msgs;
@@ -926,7 +1027,7 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
 int step_phase4(sph_mgpu *m, SphTimes *times) {
     int rc0 = resolve_mail(m);
     if (rc0) return rc0;
-    for (auto &sl : m->slabs) {
+    int rcl = for_each_slab(m, [&](Slab &sl) -> int {
         HIPM(m, hipSetDevice(sl.device));
         const int a = sl.has_dn ? sl.e_lo : sl.i0, b = sl.has_up ? sl.s_hi : sl.i1;
         if (m->shared_stream) {
@@ -962,7 +1063,9 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
         HIPM(m, hipEventRecord(sl.evCopy, sl.copy));
         sl.hostRowsCount = sl.n_own;
         sl.copyPending = true;
-    }
+        return SPH_OK;
+    });
+    if (rcl) return rcl;
     m->hostPosValid = false;
     m->step++;
     m->stats.steps++;

@@ -93,6 +93,29 @@ def test_slabs_equal_single_domain(world, transport):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,transport", [(4, "loopback"), (8, "streams")])
+def test_slab_worker_threads_equal_single_domain(world, transport, monkeypatch):
+    """SPH_MGPU_THREADS=1: the per-slab parts of a step run on one host thread per slab (message
+    rounds and the host synchronisation stay on the calling thread).  Same bits."""
+    monkeypatch.setenv("SPH_MGPU_THREADS", "1")
+    n, steps = 80000, 8
+    pos, vel = moving_state(n, 5)
+    settings = sph.default_settings(n, False)
+    want, want_pos = single_domain(settings, pos, vel, steps)
+    mg = M.MultiGpuSimulator(settings, world=world, transport=transport, recut_every=3)
+    mg.upload_state(pos, vel)
+    t = sph.Times()
+    for _ in range(steps):
+        mg.simulateAndTime(t)
+    got = mg.download_state()
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    assert_bit_equal(got["rho"], want["rho"], "rho")
+    assert_bit_equal(np.array(mg.getPosition()), want_pos, "getPosition()")
+    assert mg.stats().host_syncs == steps
+    mg.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("transport", ["loopback", "streams"])
 def test_two_layer_hops_and_tiny_faces(transport):
     """z-velocities up to 2.5 cells per step: migrants land beyond the neighbour's first
