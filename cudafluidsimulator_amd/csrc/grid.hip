@@ -47,13 +47,19 @@ void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
 // shuffles; only lanes 0 and 63 touch memory for the key next door.
 // cellRange must have been cleared beforehand (the first sort pass does it): empty cells
 // keep {0,0}.
+void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr, int nthr,
+                             int *bounds_dev, hipStream_t s);
+
 __global__ __launch_bounds__(256) void k_gather_cells(
     const float4 *__restrict__ pos_in, const float4 *__restrict__ vel_in,
     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ skeys,
     float4 *__restrict__ pos_out, float4 *__restrict__ vel_out,
-    float4 *__restrict__ pv8, int2 *__restrict__ cellRange, int n) {
+    float4 *__restrict__ pv8, int2 *__restrict__ cellRange, int n, GatherExtras X) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // riders of this launch (each was a launch of its own): the hit-stream pool's allocation
+    // cursors are cleared for the density sweep that follows ...
+    if (i < X.cursorWords) X.cursor[i] = 0ull;
     bool valid = i < n;
     uint32_t k = valid ? skeys[i] : 0xFFFFFFFFu;
     uint32_t kprev = __shfl_up(k, 1);
@@ -72,15 +78,34 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     }
     if (k != kprev) cellRange[k].x = i;
     if (k != knext) cellRange[k].y = i + 1;
+    // ... and the slab path's segment bounds: bounds[t] = first index whose key is >= thr[t]
+    // (n if there is none), bounds[nthr] = n
+    if (X.bounds) {
+        const bool first = i == 0, last = i + 1 >= n;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t >= X.nthr) break;
+            const uint32_t v = X.thr.v[t];
+            if (k >= v && (first || kprev < v)) X.bounds[t] = i;
+            if (last && k < v) X.bounds[t] = n;
+        }
+        if (last) X.bounds[X.nthr] = n;
+    }
 }
 
 void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                        const uint32_t *perm, const uint32_t *sorted_keys,
                        float4 *pos_out, float4 *vel_out, float4 *pv8, int2 *cellRange, int n,
-                       hipStream_t s) {
-    if (n <= 0) return;
-    k_gather_cells<<<(n + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, sorted_keys,
-                                                   pos_out, vel_out, pv8, cellRange, n);
+                       hipStream_t s, const GatherExtras &X) {
+    if (n <= 0) { // nothing to gather: the riders still have to happen
+        if (X.cursor && X.cursorWords > 0)
+            (void)hipMemsetAsync(X.cursor, 0, (size_t)X.cursorWords * sizeof(unsigned long long), s);
+        if (X.bounds) sph_launch_lower_bounds(sorted_keys, 0, X.thr, X.nthr, X.bounds, s);
+        return;
+    }
+    const int threads = n > X.cursorWords ? n : X.cursorWords;
+    k_gather_cells<<<(threads + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, sorted_keys,
+                                                         pos_out, vel_out, pv8, cellRange, n, X);
 }
 
 // ---- slab path: stable partition by key class (which segment of the slab's key

@@ -81,6 +81,7 @@ struct sph_handle {
     int graphKeyBuf = 0;
     hipEvent_t computeDone[2] = {nullptr, nullptr}, copyDone[2] = {nullptr, nullptr};
     bool copyPending[2] = {false, false};
+    bool cursorClean = false; // the gather launch of this grid build cleared the hit-stream cursors
     long long stepIndex = 0;
     float4 *force4 = nullptr;
     unsigned long long *pairCounter = nullptr; // device
@@ -475,6 +476,17 @@ SweepArgs make_sweep_args(sph_handle *h) {
     return A;
 }
 
+// what rides on the gather launch of a grid build: the hit-stream cursors are cleared there
+GatherExtras gather_extras(sph_handle *h) {
+    GatherExtras X;
+    if (h->maskCursor) {
+        X.cursor = h->maskCursor;
+        X.cursorWords = (int)(kCursorBytes / sizeof(unsigned long long));
+        h->cursorClean = true;
+    }
+    return X;
+}
+
 int begin_step_events(sph_handle *h) {
     StepEvents &se = h->ring[h->ringHead];
     if (se.used) {
@@ -563,20 +575,20 @@ int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
     if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
     int res = sph_sort_cells(h->ws, h->P, h->pos4[src_buf] + src_offset, count, key_bits(h), s, h->cellRange,
                              h->P.numCells); // (clears the cell table too)
+    // the segment bounds (and the element count, [nthr]) and the clearing of the hit-stream
+    // cursors ride on the gather launch
+    GatherExtras X = gather_extras(h);
+    if (nthr > 0) {
+        for (int k = 0; k < nthr; ++k) X.thr.v[k] = thresholds[k];
+        X.nthr = nthr;
+        X.bounds = bounds_dev_out ? static_cast<int *>(bounds_dev_out) : h->boundsDev;
+    }
     sph_launch_gather(h->pos4[src_buf] + src_offset, h->vel4[src_buf] + src_offset,
                       h->ws.vals[res], h->ws.keys[res], h->pos4[src_buf ^ 1],
-                      h->vel4[src_buf ^ 1], h->pv8, h->cellRange, count, s);
+                      h->vel4[src_buf ^ 1], h->pv8, h->cellRange, count, s, X);
     HIPCHK(h, hipEventRecord(pe->b, s));
     if (nthr == 4) // [zlo, zlo+1, zhi-1, zhi] * D*D: the slab's owned z-layers
         h->zLayers = (int)((thresholds[3] - thresholds[0]) / (uint32_t)(h->P.D * h->P.D));
-    if (nthr > 0) {
-        Thresholds T{};
-        for (int k = 0; k < nthr; ++k) T.v[k] = thresholds[k];
-        sph_launch_lower_bounds(h->ws.keys[res], count, T, nthr, h->boundsDev, s); // also [nthr] = count
-        if (bounds_dev_out)
-            HIPCHK(h, hipMemcpyAsync(bounds_dev_out, h->boundsDev, (nthr + 1) * sizeof(int),
-                                     hipMemcpyDeviceToDevice, s));
-    }
     HIPCHK(h, hipGetLastError());
     h->sorted = src_buf ^ 1;
     h->sortedKeyBuf = res;
@@ -682,7 +694,8 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     A.force_out = nullptr;
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
     PairEvent *pe = nullptr;
-    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, kCursorBytes, h->compute));
+    if (h->maskCursor && !h->cursorClean) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, kCursorBytes, h->compute));
+    h->cursorClean = false;
     if ((rc = pair_begin(h, &h->kt.density, &pe))) return rc;
     sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
     HIPCHK(h, hipEventRecord(pe->b, h->compute));
@@ -988,7 +1001,7 @@ int sph_phase_grid(sph_handle *h) {
     // the list sweeps take velocities from the interleaved records: no sorted vel4 copy
     float4 *velSorted = (h->opt.sweep == SPH_SWEEP_LIST && h->pv8) ? nullptr : h->vel4[c ^ 1];
     sph_launch_gather(h->pos4[c], h->vel4[c], h->ws.vals[res], h->ws.keys[res],
-                      h->pos4[c ^ 1], velSorted, h->pv8, h->cellRange, n, s);
+                      h->pos4[c ^ 1], velSorted, h->pv8, h->cellRange, n, s, gather_extras(h));
     if (ev) HIPCHK(h, hipEventRecord(ev->e[3], s));
     HIPCHK(h, hipGetLastError());
     h->sorted = c ^ 1;
@@ -1004,7 +1017,8 @@ int sph_phase_density(sph_handle *h) {
     if (h->phase != 1) return fail(h, SPH_ESTATE, "density phase needs the grid phase first");
     SweepArgs A = make_sweep_args(h);
     if (h->opt.flags & SPH_FLAG_COUNT_PAIRS) A.pairCounter = h->pairCounter;
-    if (h->maskCursor) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, kCursorBytes, h->compute));
+    if (h->maskCursor && !h->cursorClean) HIPCHK(h, hipMemsetAsync(h->maskCursor, 0, kCursorBytes, h->compute));
+    h->cursorClean = false;
     sph_launch_density(h->P, A, h->opt.math_mode, h->opt.sweep, h->compute);
     if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->e[4], h->compute));
     HIPCHK(h, hipGetLastError());

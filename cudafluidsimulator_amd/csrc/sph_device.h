@@ -84,12 +84,20 @@ int sph_sort_cells(const SortWorkspace &ws, const DevParams &P, const float4 *po
 // ---- grid build (grid.hip) ----
 void sph_launch_hash(const DevParams &P, const float4 *pos4, uint32_t *keys,
                      uint32_t *vals, int n, hipStream_t s);
+// bounds[k] = #keys < thr[k] over sorted keys (one binary search per lane)
+struct Thresholds { uint32_t v[8]; };
+// work that rides on the gather launch instead of a launch of its own (all optional)
+struct GatherExtras {
+    unsigned long long *cursor = nullptr; // hit-stream allocation cursors to clear ...
+    int cursorWords = 0;                  // ... this many 8-byte words
+    int *bounds = nullptr;                // slab path: bounds[t] = #keys < thr.v[t], bounds[nthr] = n
+    Thresholds thr{};
+    int nthr = 0;
+};
 void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                        const uint32_t *perm, const uint32_t *sorted_keys,
                        float4 *pos_out, float4 *vel_out, float4 *pv8, int2 *cellRange, int n,
-                       hipStream_t s);
-// bounds[k] = #keys < thr[k] over sorted keys (one binary search per lane)
-struct Thresholds { uint32_t v[8]; };
+                       hipStream_t s, const GatherExtras &X = GatherExtras());
 void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr, int nthr,
                              int *bounds_dev, hipStream_t s);
 void sph_launch_classify(const DevParams &P, const float4 *pos4, Thresholds thr, int nthr,
