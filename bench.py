@@ -57,6 +57,8 @@ def parse():
                     help="N > 1: step the domain as N z-slabs on ONE GPU through the C++ multi-GPU driver's "
                          "loopback transport (what the decomposition costs per slab; never `value` of a "
                          "multi-GPU run)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the full 100-step run (when --steps is not 100) and the config 2 / config 4 legs")
     ap.add_argument("--no-count-replay", action="store_true",
                     help="skip the untimed replay that counts pair tests / hits (valu_frac figures)")
     ap.add_argument("--cpu-steps", type=int, default=12,
@@ -105,6 +107,124 @@ def cpu_baseline(n, random_init, steps):
     out["single_thread"] = {"value": n / dt1, "unit": "particle-steps/s", "cores": 1,
                             "sample": f"first step only, {dt1:.1f} s"}
     return out
+
+
+def timed_run(sph, _lib, torch, s, args, K, W, device, settle=0, sweep=None, math=None, mode=None):
+    """K x simulateAndTime (or simulate) from the reference initial condition, after `settle` +
+    W untimed steps and a re-upload of the initial condition.  Returns elapsed seconds, the
+    accumulated HIP-event kernel times, the -m time table and the wall time after every step."""
+    sweep = sweep or args.sweep
+    math = math or args.math
+    mode = mode or args.mode
+    rb_flag = _lib.SPH_FLAG_MAPPED_POSITIONS if args.readback == "mapped" else 0
+
+    def one_step(sm, tm):
+        if mode == "time":
+            sm.simulateAndTime(tm)
+        else:
+            sm.simulate()
+            if mode == "display":
+                sm.getPosition()  # blocks until this frame's positions are on the host
+    sim = sph.Simulator(s, sweep=sweep, flags=rb_flag, device=device, math=math, key_order=args.key)
+    sim.setup()
+    times = sph.Times()
+    # Runtime settle, NOT part of W: with torch's bundled HIP runtime loaded, a process's 4th-7th
+    # step meets a one-off ~7 ms stall of the GPU's queues (scripts/studies/early_stall.py; never
+    # with the system runtime ./sph links) -- a fifth of a 20-step run at small n.  Twelve
+    # untimed steps take it out of the way whatever W is; then the W warm-up steps proper.
+    for _ in range(settle):
+        one_step(sim, times)
+    sim.sync()
+    if settle:
+        sim.setup()
+    for _ in range(W):
+        one_step(sim, times)
+    sim.sync()
+    sim.setup()  # back to the initial condition: timed steps are steps 1..K
+    sim.kernel_times(reset=True)
+    times = sph.Times()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    walls = []
+    for _ in range(K):
+        one_step(sim, times)
+        walls.append(time.perf_counter() - t0)
+    sim.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if os.environ.get("SPH_BENCH_STEP_WALLS"):   # diagnostic: per-step wall times on stderr
+        print("step walls (ms): " + " ".join("%.2f" % ((w - p0) * 1e3) for w, p0 in zip(walls, [0.0] + walls[:-1])),
+              file=sys.stderr)
+    out = dict(elapsed=elapsed, kt=sim.kernel_times(), times=times, walls=walls)
+    if os.environ.get("SPH_STAMPS"):
+        out["stamps"] = sim.debug_counters()
+    sim.close()
+    return out
+
+
+def count_replay(sph, _lib, s, args, K, device):
+    """Untimed replay of the same K steps with the counters on (the run is deterministic: same
+    trajectory, same pair tests and hits per step)."""
+    csim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=device,
+                         math=args.math, key_order=args.key)
+    csim.setup()
+    for _ in range(K):
+        csim.simulate()
+    ckt = csim.kernel_times()
+    st = max(int(ckt.steps), 1)
+    out = {"pair_tests": ckt.pair_tests / st, "pair_hits": ckt.pair_hits / st,
+           "pair_hits_recorded": csim.debug_counters()[15] / st}
+    csim.close()
+    return out
+
+
+def roofline_of(n_local, kt, sweep, counts):
+    """SURVEY.md 8d figures of one run: computeDensity against the HBM roof (algorithmic bytes /
+    average launch time from HIP events on the launch stream) and, because the sweeps are not
+    HBM-bound, the VALU fractions next to it."""
+    steps = max(int(kt.steps), 1)
+    dens_s, force_s = kt.density / steps, kt.force / steps
+    achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
+    roof = {"bound": "hbm",
+            "kernel": {"lds": "k_density_lds", "direct": "k_density_direct", "linked": "k_density_linked",
+                       "list": "k_density_mask_lds"}[sweep] + " (computeDensity)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_us": dens_s * 1e6,
+            "algorithmic_bytes_per_launch": DENSITY_BYTES_PER_PARTICLE * n_local,
+            "note": "the sweep is VALU-bound, not HBM-bound (SURVEY.md 8d): see valu_frac"}
+    pairs = (counts or {}).get("pair_tests") or None
+    if pairs:
+        roof["pair_tests_per_launch"] = pairs
+        roof["valu_frac"] = pairs * DENSITY_LANEOPS_PER_TEST / dens_s / VALU_PEAK_LANEOPS
+        roof["valu_frac_note"] = (f"pair tests (counted on the GPU) x {DENSITY_LANEOPS_PER_TEST} lane-ops "
+                                  f"(SURVEY.md 8d convention) / launch time / {VALU_PEAK_LANEOPS:.3g} lane-ops/s "
+                                  "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz)")
+        bodies = counts.get("pair_hits") or 0
+        recorded = counts.get("pair_hits_recorded") or 0
+        if sweep == "list" and recorded:
+            # the list sweep evaluates the pair body for recorded hits only, minus the pairs its
+            # zero-pair filter drops (no pressure on either side, same velocity: exactly +-0)
+            roof["force_hits_recorded_per_launch"] = recorded
+            roof["force_pair_bodies_per_launch"] = bodies
+            roof["force_hit_fraction"] = recorded / pairs
+            roof["force_zero_pairs_dropped"] = 1.0 - bodies / recorded
+            roof["force_valu_frac"] = bodies * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
+            roof["force_valu_frac_note"] = (
+                f"k_force_list: pair bodies actually evaluated (popcount of the hit masks after the zero-pair "
+                f"filter, counted on the GPU) x {FORCE_LANEOPS_PER_PAIR} lane-ops (SURVEY.md 8d convention) / "
+                f"launch time / VALU peak")
+        elif sweep in ("lds", "direct"):
+            # these sweeps run the test for every candidate and the body under a mask
+            roof["force_valu_frac"] = pairs * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
+            roof["force_valu_frac_note"] = "every candidate priced at the body's 55 lane-ops (tested, body masked)"
+    return roof
+
+
+def kernel_ms(kt):
+    steps = max(int(kt.steps), 1)
+    return {"hash": kt.hash / steps * 1e3, "sort": kt.sort / steps * 1e3, "gather_cells": kt.gather / steps * 1e3,
+            "density": kt.density / steps * 1e3, "force_integrate": kt.force / steps * 1e3,
+            "readback_d2h": kt.readback / steps * 1e3}
 
 
 RUNTIME_SETTLE_STEPS = 12   # see main(): untimed, before the W warm-up steps
@@ -170,7 +290,7 @@ def run_mgpu_bench(args, dist, rank, world, local_rank):
     return out
 
 
-def load_traffic(n, args):
+def load_traffic(n, args, steps):
     """HBM bytes per computeDensity launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
     command line; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for
@@ -183,8 +303,8 @@ def load_traffic(n, args):
     try:
         for e in json.load(open(path)):
             if (e["n"] == n and e["init"] == args.init and e["sweep"] == args.sweep and e["gpus"] == 1
-                    and e.get("math", "strict") == args.math and e.get("steps") == args.steps
-                    and e.get("warmup") == args.warmup):
+                    and e.get("math", "strict") == args.math and e.get("steps") == steps
+                    and e.get("current", True)):
                 return e
     except Exception:
         return None
@@ -210,15 +330,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if os.environ.get("SPH_BENCH_SINGLE_DEVICE"):
-            # rehearsal of the multi-rank path on a one-GPU box: every rank uses
-            # cuda:0 and messages bounce through the host over gloo (never a result)
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N>1 must be launched through torch.distributed.run")
@@ -237,72 +350,16 @@ def main():
     random_init = args.init == "random"
     K, W = args.steps, args.warmup
 
-    if world > 1 and os.environ.get("SPH_BENCH_SINGLE_DEVICE"):
-        from cudafluidsimulator_amd.slab import run_slab_bench   # gloo rehearsal of the Python driver
-        result = run_slab_bench(args, dist, rank, world, local_rank)
-    elif world > 1 or args.loopback_slabs > 1 or force_mgpu:
+    if world > 1 or args.loopback_slabs > 1 or force_mgpu:
         result = run_mgpu_bench(args, dist if (world > 1 or force_mgpu) else None, rank, world, local_rank)
     else:
         s = sph.default_settings(n, random_init)
         # the timed run carries no counting code at all (SPH_FLAG_COUNT_PAIRS adds atomics
         # to the density sweep); pair tests and hits come from an untimed replay below
-        rb_flag = _lib.SPH_FLAG_MAPPED_POSITIONS if args.readback == "mapped" else 0
-
-        def one_step(sm, tm):
-            if args.mode == "time":
-                sm.simulateAndTime(tm)
-            else:
-                sm.simulate()
-                if args.mode == "display":
-                    sm.getPosition()  # blocks until this frame's positions are on the host
-        sim = sph.Simulator(s, sweep=args.sweep, flags=rb_flag, device=local_rank, math=args.math,
-                            key_order=args.key)
-        sim.setup()
-        times = sph.Times()
-        # Runtime settle, NOT part of W: with torch's bundled HIP runtime loaded, a process's 4th-7th
-        # step meets a one-off ~7 ms stall of the GPU's queues (scripts/studies/early_stall.py; never
-        # with the system runtime ./sph links) -- a fifth of a 20-step run at small n.  Twelve
-        # untimed steps take it out of the way whatever W is; then the W warm-up steps proper.
-        for _ in range(RUNTIME_SETTLE_STEPS):
-            one_step(sim, times)
-        sim.sync()
-        sim.setup()
-        for _ in range(W):
-            one_step(sim, times)
-        sim.sync()
-        sim.setup()  # back to the initial condition: timed steps are steps 1..K
-        sim.kernel_times(reset=True)
-        times = sph.Times()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        walls = []
-        for _ in range(K):
-            one_step(sim, times)
-            walls.append(time.perf_counter())
-        sim.sync()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if os.environ.get("SPH_BENCH_STEP_WALLS"):   # diagnostic: per-step wall times on stderr
-            prev = t0
-            print("step walls (ms): " + " ".join("%.2f" % ((w - p0) * 1e3) for w, p0 in zip(walls, [t0] + walls[:-1])),
-                  file=sys.stderr)
-        kt = sim.kernel_times()
-        result = dict(elapsed=elapsed, kt=kt, times=times, n_total=n)
-        if os.environ.get("SPH_STAMPS"):
-            result["stamps"] = sim.debug_counters()
-        sim.close()
+        result = timed_run(sph, _lib, torch, s, args, K, W, local_rank, settle=RUNTIME_SETTLE_STEPS)
+        result["n_total"] = n
         if not args.no_count_replay:
-            # untimed replay of the same K steps with the counters on (the run is
-            # deterministic: same trajectory, same pair tests and hits per step)
-            csim = sph.Simulator(s, sweep=args.sweep, flags=_lib.SPH_FLAG_COUNT_PAIRS, device=local_rank,
-                                 math=args.math, key_order=args.key)
-            csim.setup()
-            for _ in range(K):
-                csim.simulate()
-            ckt = csim.kernel_times()
-            result["pair_tests"] = ckt.pair_tests / max(int(ckt.steps), 1)
-            result["pair_hits"] = ckt.pair_hits / max(int(ckt.steps), 1)
-            csim.close()
+            result.update(count_replay(sph, _lib, s, args, K, local_rank))
         if args.sweep == "list" and args.math == "strict" and not args.no_linked_leg:
             # secondary figure: the reference's own neighbour structure (per-cell
             # linked lists, no sort) on this GPU, same K steps (not `value`)
@@ -338,6 +395,30 @@ def main():
             fsim.sync()
             result["fast_elapsed"] = time.perf_counter() - f0
             fsim.close()
+        if not args.no_extra_legs and args.mode == "time" and args.readback == "copy":
+            # The metric BASELINE.json names is the 100-step loop of main.cpp:68-76.  Whatever K the
+            # command line asked for, the full loop runs too (0.2 s) and is reported as `full_run_100`.
+            if K == FULL_RUN_STEPS:
+                result["full100"] = dict(result)
+            else:
+                r100 = timed_run(sph, _lib, torch, s, args, FULL_RUN_STEPS, min(W, 5), local_rank)
+                if not args.no_count_replay:
+                    r100.update(count_replay(sph, _lib, s, args, FULL_RUN_STEPS, local_rank))
+                r100["n_total"] = n
+                result["full100"] = r100
+            # one-line legs for the other single-GPU configurations of BASELINE.json (defaults only)
+            if n == 4194304 and random_init and args.sweep == "list" and args.math == "strict":
+                legs = {}
+                for name, (ln, lk, lw) in {"config2_n262144_100steps": (262144, 100, 5),
+                                           "config4_n16777216_single_gpu_10steps": (16777216, 10, 2)}.items():
+                    ls = sph.default_settings(ln, True)
+                    lr = timed_run(sph, _lib, torch, ls, args, lk, lw, local_rank)
+                    legs[name] = {"workload": f"-n {ln} -i random -m time, first {lk} steps" if lk != 100 else
+                                  f"-n {ln} -i random -m time (100 steps)",
+                                  "value": ln * lk / lr["elapsed"], "unit": "particle-steps/s",
+                                  "ms_per_step": lr["elapsed"] / lk * 1e3, "steps": lk, "warmup": lw,
+                                  "kernel_ms_per_step": kernel_ms(lr["kt"])}
+                result["legs"] = legs
 
     if world > 1 or force_mgpu:
         t = torch.tensor([result["elapsed"]], device="cuda", dtype=torch.float64)
@@ -350,39 +431,8 @@ def main():
         if kt is None:  # the C++ multi-GPU driver reports per-slab kernel time only
             from cudafluidsimulator_amd import SphKernelTimes
             kt = SphKernelTimes()
-        steps = max(int(kt.steps), 1)
-        dens_s = kt.density / steps      # avg launch duration of computeDensity (HIP events)
-        force_s = kt.force / steps
         n_local = result.get("n_local", n)
-        pairs = result.get("pair_tests") or None
-        achieved = DENSITY_BYTES_PER_PARTICLE * n_local / dens_s / 1e9 if dens_s > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": {"lds": "k_density_lds", "direct": "k_density_direct",
-                                                   "linked": "k_density_linked",
-                                                   "list": "k_density_mask_lds"}[args.sweep] + " (computeDensity)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_us": dens_s * 1e6,
-                "algorithmic_bytes_per_launch": DENSITY_BYTES_PER_PARTICLE * n_local,
-                "note": "the sweep is VALU-bound, not HBM-bound (SURVEY.md 8d): see valu_frac"}
-        if pairs:
-            roof["pair_tests_per_launch"] = pairs
-            roof["valu_frac"] = pairs * DENSITY_LANEOPS_PER_TEST / dens_s / VALU_PEAK_LANEOPS
-            roof["valu_frac_note"] = (f"pair tests (counted on the GPU) x {DENSITY_LANEOPS_PER_TEST} lane-ops "
-                                      f"(SURVEY.md 8d convention) / launch time / {VALU_PEAK_LANEOPS:.3g} lane-ops/s "
-                                      "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz)")
-            hits = result.get("pair_hits") or 0
-            if args.sweep == "list" and hits:
-                # the list sweep evaluates the pair body for recorded hits only
-                roof["force_pair_bodies_per_launch"] = hits
-                roof["force_hit_fraction"] = hits / pairs
-                roof["force_valu_frac"] = hits * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
-                roof["force_valu_frac_note"] = (
-                    f"k_force_list: pair bodies actually evaluated (popcount of the hit masks, counted on "
-                    f"the GPU) x {FORCE_LANEOPS_PER_PAIR} lane-ops (SURVEY.md 8d convention) / launch time "
-                    f"/ VALU peak; the kernel is bound by its divergent gathers, not by VALU issue (DESIGN.md)")
-            elif args.sweep in ("lds", "direct"):
-                # these sweeps run the test for every candidate and the body under a mask
-                roof["force_valu_frac"] = pairs * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
-                roof["force_valu_frac_note"] = "every candidate priced at the body's 55 lane-ops (tested, body masked)"
+        roof = roofline_of(n_local, kt, args.sweep, result)
         full = K == FULL_RUN_STEPS
         out = {
             "metric": ("particle-steps/sec (100-step -m time)" if full else
@@ -390,8 +440,8 @@ def main():
             "full_run": full,
             "full_run_note": None if full else (
                 f"steps 1..{K} only: work per step grows 4.7x over the 100 steps (pressure and floor "
-                "contact start at step ~45), so this is not the 100-step figure; see DESIGN.md / profiles/ "
-                "for the full run"),
+                "contact start at step ~45), so this is not the 100-step figure: that one is `full_run_100` "
+                "below, measured in this same process"),
             "value": result["n_total"] * K / elapsed,
             "unit": "particle-steps/s",
             "n_gpus": world, "steps": K, "warmup": W,
@@ -407,14 +457,25 @@ def main():
                                       else "FAST fp32 math (FMA, approximate rcp/rsq; 1e-5 tolerance mode)"),
                        "sweep": args.sweep,
                        "parallelism": "single domain" if world == 1 else
-                       (f"z-slabs x{world}, one process per GPU, C++ driver + RCCL send/recv halo" if not os.environ.get("SPH_BENCH_SINGLE_DEVICE")
-                        else f"REHEARSAL: z-slabs x{world} on ONE GPU, gloo via host")},
+                       f"z-slabs x{world}, one process per GPU, C++ driver + RCCL send/recv halo"},
             "roofline": roof,
-            "kernel_ms_per_step": {"hash": kt.hash / steps * 1e3, "sort": kt.sort / steps * 1e3,
-                                   "gather_cells": kt.gather / steps * 1e3,
-                                   "density": dens_s * 1e3, "force_integrate": force_s * 1e3,
-                                   "readback_d2h": kt.readback / steps * 1e3},
+            "kernel_ms_per_step": kernel_ms(kt),
         }
+        if "full100" in result:
+            f = result["full100"]
+            froof = roofline_of(n, f["kt"], args.sweep, f)
+            ftr = load_traffic(n, args, steps=FULL_RUN_STEPS) if world == 1 else None
+            if ftr:
+                froof["traffic"] = ftr["bytes_per_launch"]
+                froof["traffic_source"] = ftr["source"]
+            out["full_run_100"] = {
+                "metric": "particle-steps/sec (100-step -m time)", "value": n * FULL_RUN_STEPS / f["elapsed"],
+                "unit": "particle-steps/s", "ms_per_step": f["elapsed"] / FULL_RUN_STEPS * 1e3,
+                "steps": FULL_RUN_STEPS, "kernel_ms_per_step": kernel_ms(f["kt"]), "roofline": froof,
+                "note": "the full loop of main.cpp:68-76 from the reference initial condition, run in this same "
+                        "process whatever --steps is (`value` above is the --steps window)"}
+        if "legs" in result:
+            out["other_configs"] = result["legs"]
         if "times" in result:
             t = result["times"]
             out["m_time_table_s"] = {"grid_construction": t.buildGrid, "sph_update": t.sphUpdate,
@@ -440,7 +501,7 @@ def main():
                         "algorithm on MI355X' that can be run (the CUDA source cannot). Same K steps, same "
                         "input; summation order is a race, results match the oracle to 1e-5 relative "
                         "(tests/test_gpu_linked.py). Not `value`."}
-        tr = load_traffic(result["n_total"], args) if world == 1 else None
+        tr = load_traffic(result["n_total"], args, steps=K) if world == 1 else None
         if tr:
             roof["traffic"] = tr["bytes_per_launch"]
             roof["traffic_steps"] = tr["steps"]
@@ -458,6 +519,15 @@ def main():
                 out["config"]["parallelism"] = f"LOOPBACK: {args.loopback_slabs} z-slabs on ONE GPU (decomposition cost study)"
         if args.cpu_steps > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_particles or n, random_init, args.cpu_steps)
+            # the GPU over the SAME window (steps 1..cpu_steps of the same run), from the per-step wall
+            # times of a timed loop above (-m time waits for the compute stream after every step)
+            src = result if K >= args.cpu_steps else result.get("full100")
+            if src and "walls" in src and len(src["walls"]) >= args.cpu_steps and not args.cpu_particles and args.mode == "time":
+                w = src["walls"][args.cpu_steps - 1]
+                out["cpu_baseline"]["gpu_same_window"] = {
+                    "value": n * args.cpu_steps / w, "unit": "particle-steps/s",
+                    "ratio": n * args.cpu_steps / w / out["cpu_baseline"]["value"],
+                    "window": f"steps 1..{args.cpu_steps} of the same run, wall time of the -m time loop"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -82,6 +82,7 @@ struct Slab {
     int *pinned = nullptr;        // host: own Hdr (8) | rx Hdr x2 (16) | sort bounds (8)
     F4 *hostRows = nullptr;       // pinned: owned pos4 rows of the last step
     int hostRowsCount = 0;
+    bool rowsStale = true;        // hostRows does not hold the owned rows (fresh upload, re-cut): refill on demand
     bool copyPending = false;
     ncclComm_t comm_nccl = nullptr;
     int cur = 0, off = 0, n_own = 0;
@@ -599,6 +600,7 @@ int distribute(sph_mgpu *m, const std::vector<F4> &p4, const std::vector<F4> &v4
         sl.expectValid = false;
         sl.copyPending = false;
         sl.hostRowsCount = 0;
+        sl.rowsStale = true; // hostRows served as the upload's staging buffer
         sl.status = 0;
     }
     m->hostPosValid = false;
@@ -639,6 +641,8 @@ int upload_common(sph_mgpu *m, const float *pos, const float *vel, int n) {
         p4[i] = {x, y, z, idbits};
         v4[i] = vel ? F4{vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.f} : F4{0.f, 0.f, 0.f, 0.f};
     }
+    m->phase = 0; // a fresh state also clears whatever a failed step left half-done
+    m->overflow = false;
     int rc = distribute(m, p4, v4);
     if (rc) return rc;
     m->ready = true;
@@ -1062,6 +1066,7 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
                                    hipMemcpyDeviceToHost, sl.copy));
         HIPM(m, hipEventRecord(sl.evCopy, sl.copy));
         sl.hostRowsCount = sl.n_own;
+        sl.rowsStale = false;
         sl.copyPending = true;
         return SPH_OK;
     });
@@ -1148,13 +1153,18 @@ const float *sph_mgpu_positions_host(sph_mgpu *m) {
             m->err = "stream synchronize failed";
             return nullptr;
         }
-        if (m->step == 0) { // before the first step: the uploaded state itself
+        if (sl.rowsStale) { // before the first step, or right after a re-cut: the uploaded state itself
+            if (hipStreamSynchronize(sl.s) != hipSuccess) {
+                m->err = "stream synchronize failed";
+                return nullptr;
+            }
             if (sl.n_own && hipMemcpy(sl.hostRows, sl.pos[sl.cur] + sl.off, (size_t)sl.n_own * sizeof(F4),
                                       hipMemcpyDeviceToHost) != hipSuccess) {
                 m->err = "hipMemcpy failed";
                 return nullptr;
             }
             sl.hostRowsCount = sl.n_own;
+            sl.rowsStale = false;
         }
         for (int i = 0; i < sl.hostRowsCount; ++i) {
             const F4 &p = sl.hostRows[i];

@@ -92,6 +92,9 @@ struct sph_handle {
     SphKernelTimes kt{};
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
+    uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
+    bool useQuiet = true;            // SPH_ZERO_PAIR_FILTER=0 switches the filter off (A/B; same results)
+    uint64_t hitsRecorded = 0;       // SPH_FLAG_COUNT_PAIRS: hits in the stream, before the filter
     unsigned long long *maskCursor = nullptr;
     unsigned long long maskCapacity = 0; // quads (16 B)
     bool external = false;  // pos4/vel4 are caller-owned (sph_bind_buffers)
@@ -102,6 +105,7 @@ struct sph_handle {
     int pairHead = 0;
     int zLayers = 0;        // occupied z-layers of the (owned) particles: sizes xcd_tile()'s chunks
     int tileChunkEnv = -1;  // SPH_TILE_CHUNK: -1 auto, 0 contiguous eighths, >0 tiles per chunk
+    int tileRotate = 0;     // SPH_XCD_ROTATE: xcd_tile()'s rotation period in groups (z-layers), 0 = off
     bool ready = false;     // state uploaded
     bool gridValid = false; // sorted streams + cell table match `sorted`
     int phase = 0;          // 0 idle, 1 grid done, 2 density done, 3 force done
@@ -295,6 +299,11 @@ int alloc_device(sph_handle *h) {
         HIPCHK(h, hipMemset(h->maskOff, 0xFF, hdrWords * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->maskCursor, kCursorBytes));
         HIPCHK(h, hipMemset(h->maskCursor, 0, kCursorBytes));
+        // one bit per sorted row + the word a 32-row window may reach into
+        const size_t quietWords = 2 * ((cap + 63) / 64) + 2;
+        HIPCHK(h, hipMalloc(&h->quiet, quietWords * sizeof(uint32_t)));
+        HIPCHK(h, hipMemset(h->quiet, 0, quietWords * sizeof(uint32_t)));
+        if (const char *e = getenv("SPH_ZERO_PAIR_FILTER")) h->useQuiet = atoi(e) != 0;
     }
     HIPCHK(h, hipMalloc(&h->boundsDev, 16 * sizeof(int)));
     HIPCHK(h, hipMalloc(&h->partTiles, sph_partition_tiles((int)cap) * 9 * sizeof(int)));
@@ -465,11 +474,14 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.patchHalo = 0;
     A.n_all = h->n;
     A.tileChunk = tile_chunk(h, h->n, h->zLayers);
+    A.tileRotate = h->tileRotate;
     A.maskPool = h->maskPool;
     A.maskOff = h->maskOff;
     A.maskCursor = h->maskCursor;
     A.maskCapacity = h->maskCapacity;
     A.pv8 = h->pv8;
+    // single domain only: a slab's owned range starts anywhere and its halo densities arrive later
+    A.quiet = (h->useQuiet && !h->external && h->n > 0) ? h->quiet : nullptr;
     A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
     A.listNext = reinterpret_cast<const int *>(h->ws.vals[0]);
@@ -876,6 +888,7 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
     if ((h->opt.flags & SPH_FLAG_EXTERNAL_STATE) && h->opt.capacity > 0) h->cap = h->opt.capacity;
     else h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
     if (const char *e = getenv("SPH_TILE_CHUNK")) h->tileChunkEnv = atoi(e); // tuning studies
+    if (const char *e = getenv("SPH_XCD_ROTATE")) h->tileRotate = atoi(e);
     fill_params(h);
     int rc = SPH_OK;
     do {
@@ -939,6 +952,7 @@ void sph_destroy(sph_handle *h) {
     if (h->maskPool) (void)hipFree(h->maskPool);
     if (h->maskOff) (void)hipFree(h->maskOff);
     if (h->maskCursor) (void)hipFree(h->maskCursor);
+    if (h->quiet) (void)hipFree(h->quiet);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
     if (h->partTiles) (void)hipFree(h->partTiles);
     if (h->boundsHost) (void)hipHostFree(h->boundsHost);
@@ -1431,9 +1445,11 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
         HIPCHK(h, hipMemcpy(h->pairHost, h->pairCounter, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         h->kt.pair_tests = h->pairHost[0];
         h->kt.pair_hits = 0;
+        h->hitsRecorded = 0;
         for (int sh = 0; sh < 256; ++sh) { // sharded counters (one address would serialise the waves)
             h->kt.pair_tests += h->pairHost[16 + sh * 16];
-            h->kt.pair_hits += h->pairHost[16 + sh * 16 + 15];
+            h->kt.pair_hits += h->pairHost[16 + sh * 16 + 14];   // bodies evaluated (after the zero-pair filter)
+            h->hitsRecorded += h->pairHost[16 + sh * 16 + 15];   // hits in the stream
         }
     }
     *out = h->kt;

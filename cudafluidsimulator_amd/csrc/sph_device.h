@@ -146,12 +146,16 @@ struct SweepArgs {
     int n_all;
     int patchHalo;            // list sweep force launch: copy the halo rows' vel4 into pv8 first
     int tileChunk;            // xcd_tile(): 256-particle tiles per chunk (1/8 z-layer), 0 = eighths
+    int tileRotate;           // xcd_tile(): the chunk -> XCD assignment moves on by one every so many groups (0 = fixed)
     // SPH_SWEEP_LIST: hit bit streams handed from the density to the force sweep
     uint32_t *maskPool;               // pool of quads: two (first candidate, 32-bit mask) pairs each
     uint32_t *maskOff;                // per 64-particle wave: {first quad or ~0u, quads per lane}
     unsigned long long *maskCursor;   // quads handed out this step, per sub-pool: [SL_POOL_SHARDS][SL_CURSOR_STRIDE]
     unsigned long long maskCapacity;  // pool size in quads
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
+    uint32_t *quiet;                  // zero-pair filter (may be null = off): bit j of this array is set when sorted row j
+                                      // has no pressure and moves with the reference velocity (the last sorted row's); a
+                                      // hit between two such rows adds exactly +-0 to the force and is dropped unread
     int rhoToVel4;                    // list sweep: also store rho in vel4.w (slab halo exchange B)
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
     const int *listHead;              // [numCells] first particle of the cell or -1

@@ -312,14 +312,21 @@ __device__ __forceinline__ void store_particle(const SweepArgs &A, int i, float4
 //    through the layers together, each on its own y-band, and an XCD's working
 //    set is that band of the ~9 layers it has in flight (1.8 MB): the records of
 //    the layers above and below are still in its L2 when it reaches them.
-__device__ __forceinline__ int xcd_tile(int b, int nb, int C) {
+//  * rot > 0: chunk x of group g goes to XCD (x - g / rot) mod 8 instead of XCD x.  A group is
+//    about one z-layer, sorted y-major: once the fluid has reached the floor, the dense rows of
+//    EVERY layer sit in its first chunks, and with a fixed chunk -> XCD assignment the same one to
+//    four XCDs would carry all of them (they are most of the work late in a run) while the rest
+//    idle through the sparse cloud.  Rotating every `rot` layers spreads the floor over all eight
+//    and keeps `rot` consecutive layers of a band on one XCD (the L2 reuse above).
+__device__ __forceinline__ int xcd_tile(int b, int nb, int C, int rot = 0) {
     int base = 0, R = nb, r = b;
     if (C > 0) {
         const int G = 8 * C;
         const int ng = nb / G, g = b / G;
         if (g < ng) {
             r = b - g * G;
-            return g * G + (r & 7) * C + (r >> 3);
+            const int x = rot > 0 ? ((r & 7) + g / rot) & 7 : (r & 7);
+            return g * G + x * C + (r >> 3);
         }
         base = ng * G; // the tail (< one group) is dealt in contiguous eighths
         R = nb - base;

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 *stage = stageAll[w];
     SW_STAMP(t0);
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + threadIdx.x;
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk, A.tileRotate) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
     __shared__ uint32_t queueAll[SW_WAVES][SW_QCAP * SPH_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     SW_STAMP(t0);
-    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk) * blockDim.x + threadIdx.x;
+    const int i = A.i_begin + xcd_tile(blockIdx.x, gridDim.x, A.tileChunk, A.tileRotate) * blockDim.x + threadIdx.x;
     const bool valid = i < A.i_end;
     const int iSafe = valid ? i : A.i_begin; // i_end > i_begin whenever we are launched
     float4 pi = A.pos4[iSafe];

@@ -94,6 +94,35 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_K1_WAVES
 #define SL_K1_WAVES 6 // resident waves per SIMD asked for (caps the VGPR budget at 80); measured: 5..8 the same
 #endif
+// ---- zero-pair filter ("quiet" rows) ----
+// kernelUpdateForces adds, for a neighbour j of i, a pressure term proportional to
+// (p_i + p_j) and a viscosity term proportional to (v_j - v_i) (simulator.cu:223-251).
+// When neither row is under pressure and both move with the same velocity, both terms are
+// exactly +-0 and the accumulators (never -0) do not change: the pair can be dropped without
+// reading j at all.  That is every pair of a body of fluid in free fall -- all of the
+// reference's `-i random` run until the cloud reaches the floor, and the part of it still
+// falling afterwards.  The density sweep leaves one bit per sorted row: "no pressure, and the
+// velocity equals the last sorted row's" (any reference velocity is correct; the last row sits
+// at the top of the highest z-layer, the last place gravity empties); the force sweep of a
+// quiet row clears the quiet candidates out of its hit masks, 32 at a time.
+__device__ __forceinline__ bool sl_is_quiet(float rho, const float4 &v, const float4 &vref) {
+    const float prs = fmaxf(0.f, SPH_GAS_CONSTANT * (rho - SPH_REST_DENSITY));
+    return prs == 0.f && v.x == vref.x && v.y == vref.y && v.z == vref.z;
+}
+// one 64-bit word per 64-row wave (rows [i - lane, i - lane + 64), i - lane a multiple of 64)
+__device__ __forceinline__ void sl_store_quiet(const SweepArgs &A, int i, bool valid, float rho, int lane) {
+    const float4 vref = A.pv8[2 * (size_t)(A.n_all - 1) + 1];
+    bool q = false;
+    if (valid) q = sl_is_quiet(rho, A.pv8[2 * (size_t)i + 1], vref);
+    const unsigned long long qb = __ballot(q);
+    if (lane == 0) reinterpret_cast<unsigned long long *>(A.quiet)[(i - lane) >> 6] = qb;
+}
+// quiet bits of rows [j, j + 32)
+__device__ __forceinline__ uint32_t sl_quiet_window(const uint32_t *__restrict__ quiet, uint32_t j) {
+    const uint32_t lo = quiet[j >> 5], hi = quiet[(j >> 5) + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, j & 31u);
+}
+
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
@@ -119,7 +148,7 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
 #if SW_STAMPS
     unsigned long long accStage = 0, accTest = 0;
 #endif
-    const int wv = xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K1_THREADS)) * (SL_K1_THREADS / SPH_WAVE) + w;
+    const int wv = xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K1_THREADS), A.tileRotate) * (SL_K1_THREADS / SPH_WAVE) + w;
     const int i = A.i_begin + wv * SPH_WAVE + lane;
     const bool valid = i < A.i_end;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
@@ -384,6 +413,7 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
         if (A.rhoToVel4) A.vel4[i].w = rho;
         A.pv8[2 * (size_t)i + 1].w = rho;
     }
+    if (A.quiet) sl_store_quiet(A, i, valid, rho, lane);
 #if SW_STAMPS
     {
         SL_STAMP(t3);
@@ -426,7 +456,7 @@ void k_force_list(DevParams P, SweepArgs A) {
     const int tileIdx = ((rb - A.i_origin) >> 6) / (SL_K2_THREADS / SPH_WAVE) +
                         xcd_tile(second ? (int)blockIdx.x - A.nblk1 : (int)blockIdx.x,
                                  second ? (int)gridDim.x - A.nblk1 : A.nblk1,
-                                 A.tileChunk * (256 / SL_K2_THREADS));
+                                 A.tileChunk * (256 / SL_K2_THREADS), A.tileRotate);
     const int i = A.i_origin + tileIdx * blockDim.x + threadIdx.x;
     const bool valid = i >= rb && i < re;
     const int iSafe = valid ? i : rb;
@@ -469,25 +499,40 @@ void k_force_list(DevParams P, SweepArgs A) {
         // with a zero mask (or after Q quads).  pop() returns the next hit's sorted
         // index, or the particle itself once the stream is exhausted (dist = 0 gates
         // every term: exact no-op).
-        const uint4 *stream4 = reinterpret_cast<const uint4 *>(A.maskPool) + baseq + (threadIdx.x & 63);
-        const int nq = valid ? Q : 0;
-        int wq = 0;
+        // (uniform base + one 32-bit per-lane quad index: a per-lane 64-bit pointer, a quad counter and a
+        // per-lane end cost three more VGPRs, and the 73rd costs the seventh resident wave)
+        const uint4 *const sbase = reinterpret_cast<const uint4 *>(A.maskPool) + baseq;
+        const uint32_t send = (uint32_t)Q * SPH_WAVE;                           // uniform: end of the wave's quads
+        uint32_t sidx = valid ? (threadIdx.x & 63u) : send;                      // this lane's next quad
         uint32_t m = 0, mq[2] = {0u, 0u};
         int jb = 0, jq[2] = {0, 0};
         bool live = true;
+        // zero-pair filter: a quiet row drops its quiet candidates (see sl_is_quiet)
+        const bool qi = A.quiet && valid && ((A.quiet[i >> 5] >> (i & 31)) & 1u);
+        // post-condition: mq[0] != 0, or the lane's sequence is exhausted
         auto fetch = [&]() {
-            if (wq < nq) {
-                const uint4 t = stream4[(size_t)wq * SPH_WAVE];
+            while (sidx < send) {
+                uint4 t = sbase[sidx];
+                sidx = (t.w == 0u) ? send : sidx + SPH_WAVE; // a zero mask ends the sequence
+                if (qi) {
+                    t.y &= ~sl_quiet_window(A.quiet, t.x);
+                    t.w &= ~sl_quiet_window(A.quiet, t.z);
+                }
+                if (t.y == 0u) { // first pair empty (filtered, or the terminator): the second moves up
+                    t.x = t.z;
+                    t.y = t.w;
+                    t.w = 0u;
+                }
                 jq[0] = (int)t.x;
                 mq[0] = t.y;
                 jq[1] = (int)t.z;
                 mq[1] = t.w;
-                wq = (t.w == 0u) ? nq : wq + 1; // a zero mask ends the sequence
+                if (t.y != 0u) break;
             }
         };
         fetch();
         auto pop = [&]() -> int {
-            if (m == 0) { // next pair; stored masks are never 0, so mq[0] == 0 means "queue empty"
+            if (m == 0) { // next pair; queued masks are never 0, so mq[0] == 0 means "queue empty"
                 m = mq[0];
                 jb = jq[0];
                 mq[0] = mq[1];
@@ -585,22 +630,30 @@ void k_force_list(DevParams P, SweepArgs A) {
 // production kernels carry no counting code.
 __global__ __launch_bounds__(256) void k_count_hits(SweepArgs A) {
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = 0;
+    uint32_t n = 0, dropped = 0;
     if (i < A.i_end) {
         const int wv = (i - A.i_origin) >> 6;
         const uint32_t baseq = A.maskOff[2 * (size_t)wv];
         const int Q = (int)A.maskOff[2 * (size_t)wv + 1];
         if (baseq != SL_NONE) {
             const uint4 *q4 = reinterpret_cast<const uint4 *>(A.maskPool) + baseq + (threadIdx.x & 63);
+            const bool qi = A.quiet && ((A.quiet[i >> 5] >> (i & 31)) & 1u);
             for (int q = 0; q < Q; ++q) {
                 const uint4 t = q4[(size_t)q * SPH_WAVE];
                 n += (uint32_t)__builtin_popcount(t.y) + (uint32_t)__builtin_popcount(t.w);
+                if (qi) // what the zero-pair filter drops (k_force_list)
+                    dropped += (uint32_t)__builtin_popcount(t.y & sl_quiet_window(A.quiet, t.x)) +
+                               (uint32_t)__builtin_popcount(t.w & sl_quiet_window(A.quiet, t.z));
                 if (t.w == 0u) break;
             }
         }
     }
     n = wave_sum_u32(n);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(A.pairCounter + 16 + (blockIdx.x & 255) * 16 + 15, (unsigned long long)n);
+    dropped = wave_sum_u32(dropped);
+    if ((threadIdx.x & 63) == 0 && n) {
+        atomicAdd(A.pairCounter + 16 + (blockIdx.x & 255) * 16 + 15, (unsigned long long)n);
+        atomicAdd(A.pairCounter + 16 + (blockIdx.x & 255) * 16 + 14, (unsigned long long)(n - dropped));
+    }
 }
 
 void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {

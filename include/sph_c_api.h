@@ -110,9 +110,12 @@ typedef struct SphKernelTimes {
     double hash, sort, gather, density, force, readback;
     uint64_t pair_tests; /* sum over steps, if SPH_FLAG_COUNT_PAIRS */
     int64_t steps;
-    uint64_t pair_hits;  /* SPH_FLAG_COUNT_PAIRS + SPH_SWEEP_LIST: candidates inside the support
-                            radius = pair bodies the force sweep evaluates (popcount of the
-                            recorded hit masks), summed over steps; 0 for the other sweeps */
+    uint64_t pair_hits;  /* SPH_FLAG_COUNT_PAIRS + SPH_SWEEP_LIST: pair bodies the force sweep
+                            evaluates = candidates inside the support radius (popcount of the
+                            recorded hit masks) minus the pairs its zero-pair filter drops
+                            (neither row under pressure, same velocity: the pair adds exactly
+                            +-0), summed over steps; 0 for the other sweeps.  The unfiltered
+                            count is word 15 of sph_debug_counters() */
 } SphKernelTimes;
 
 typedef struct sph_handle sph_handle;

@@ -1,4 +1,10 @@
-"""z-slab decomposition of the SPH step across GPUs (one process per GPU).
+"""REHEARSAL ONLY (test infrastructure, lives under tests/): the z-slab protocol of
+cudafluidsimulator_amd/csrc/mgpu.cpp restated over torch.distributed so that it can run on
+CPU ranks (gloo, world 2/3) against the oracle backend.  The product's multi-GPU driver is
+the C++ library libsph_mgpu.so (include/sph_mgpu.h); nothing in the package or bench.py
+imports this file.
+
+z-slab decomposition of the SPH step across GPUs (one process per GPU).
 
 The reference is single-GPU; this is new design.  The box is cut
 into slabs of whole cell layers along z -- z is the slowest digit of the
@@ -39,8 +45,8 @@ import time
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import SphError, SphKernelTimes, SphOptions, load_library
+from cudafluidsimulator_amd import _lib
+from cudafluidsimulator_amd._lib import SphError, SphKernelTimes, SphOptions, load_library
 
 
 # --------------------------------------------------------------------------
@@ -561,68 +567,3 @@ def default_face_cap(pos4, h, D):
     layer plus the step's migrants; a fuller face falls back to a second message)."""
     hist = np.bincount(layer_of(pos4[:, 2], h, D), minlength=D)
     return int(1.25 * int(hist.max())) + 4096
-
-
-def run_slab_bench(args, dist, rank, world, local_rank):
-    """bench.py's N>1 leg: strong scaling of one n-particle domain over `world`
-    GPUs.  Returns rank-local timing; bench.py takes the max over ranks."""
-    from .simulator import default_settings
-    n = args.particles
-    settings = default_settings(n, args.init == "random")
-    D = int(settings.numCellsPerDim)
-    pos4, vel4 = make_initial(settings)
-    bounds, parts = split_initial(pos4, vel4, settings.h, D, world)
-    zlo, zhi = bounds[rank]
-    my_pos, my_vel = parts[rank]
-    cap = int(max(len(p[0]) for p in parts) * 1.6) + 65536
-    backend = HipSlabBackend(settings, cap, device=local_rank, sweep=args.sweep, flags=0)
-    slab = Slab(backend, rank, world, zlo, zhi, D, face_cap=min(default_face_cap(pos4, settings.h, D), cap))
-    tr = DistTransport(dist, rank, world, backend.device, via_cpu=dist.get_backend() == "gloo")
-    # Per-step position read-back (simulator.cu:479) of the owned particles, off the
-    # compute stream like the single-domain path: a device-side snapshot (a few
-    # microseconds) and then the PCIe copy on its own stream, double-buffered, so step
-    # k+1 computes while step k's positions travel.
-    host = torch.empty((cap, 4), dtype=torch.float32).pin_memory()
-    snap = [torch.empty((cap, 4), dtype=torch.float32, device=backend.device) for _ in range(2)]
-    copy_stream = torch.cuda.Stream(device=backend.device)
-    snap_free = [None, None]   # event: the D2H copy out of snap[i] has finished
-    counter = [0]
-
-    def reload():
-        slab.load(torch.from_numpy(my_pos).to(backend.device), torch.from_numpy(my_vel).to(backend.device))
-
-    def one_step():
-        step_distributed(slab, tr)
-        p, _ = slab.owned()
-        i = counter[0] & 1
-        counter[0] += 1
-        cur = torch.cuda.current_stream(backend.device)
-        if snap_free[i] is not None:
-            cur.wait_event(snap_free[i])
-        snap[i][:len(p)].copy_(p)
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        copy_stream.wait_event(ready)
-        with torch.cuda.stream(copy_stream):
-            host[:len(p)].copy_(snap[i][:len(p)], non_blocking=True)
-            snap_free[i] = torch.cuda.Event()
-            snap_free[i].record(copy_stream)
-
-    reload()
-    # at least one untimed step: the first P2P call builds the RCCL communicators
-    for _ in range(max(args.warmup, 1)):
-        one_step()
-    reload()
-    backend.kernel_times(reset=True)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kt = backend.kernel_times()
-    n_local = slab.n_own
-    backend.close()
-    return dict(elapsed=elapsed, kt=kt, n_total=n, n_local=n_local, overflow_rounds=slab.overflows)

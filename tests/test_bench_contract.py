@@ -32,6 +32,7 @@ def test_bench_needs_a_gpu(have_gpu):
 @pytest.mark.gpu
 def test_single_gpu_line():
     d = run_bench("-n", "262144", "--steps", "6", "--warmup", "2", "--cpu-steps", "2", "--no-linked-leg")
+    assert "other_configs" not in d   # the config 2 / config 4 legs ride on the default command only
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -42,6 +43,15 @@ def test_single_gpu_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None and "traffic_note" in r          # no PMC run of THIS command
     assert 0 < r["force_hit_fraction"] < 1 and r["force_valu_frac"] < 1
+    # free fall: every recorded hit is an exact-zero pair and the filter drops it
+    assert r["force_pair_bodies_per_launch"] <= r["force_hits_recorded_per_launch"]
+    # the metric BASELINE.json names (the 100-step loop) is always measured, whatever --steps is
+    f = d["full_run_100"]
+    assert f["steps"] == 100 and f["value"] > 0 and f["roofline"]["bound"] == "hbm"
+    assert abs(f["value"] - 262144 * 100 / (f["ms_per_step"] * 1e-3 * 100)) < 1e-3 * f["value"]
+    assert set(f["kernel_ms_per_step"]) >= {"sort", "density", "force_integrate"}
+    g = d["cpu_baseline"].get("gpu_same_window")
+    assert g and g["ratio"] > 10
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["steps"] == 2 and "-march=native" in c["build"] and c["value"] > 0
     assert d["value"] > 10 * c["value"]

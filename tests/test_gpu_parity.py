@@ -439,3 +439,70 @@ def test_odd_particle_counts(n):
         if n:
             compare_state(sim, ref, f"n={n} {sweep}")
         sim.close()
+
+
+# ---- zero-pair filter of the list force sweep (sweeps_list.hip: sl_is_quiet) ----
+
+def co_moving_mixture(seed):
+    """A cloud in which most particles share ONE velocity (quiet rows: their mutual pairs add
+    exactly +-0 and are dropped unread) around (a) a block dense enough for pressure that moves
+    with the SAME velocity (quiet velocity, but pressure: its pairs must be kept), (b) particles
+    with velocities of their own scattered through the cloud, (c) a particle at rest."""
+    rng = np.random.default_rng(seed)
+    n = 40000
+    pos = rng.uniform(2.0, 6.0, (n, 3)).astype(np.float32)
+    vel = np.tile(np.array([0.25, -1.5, 0.125], np.float32), (n, 1))
+    blk = dense_block(14, spacing=0.03, origin=(3.0, 3.0, 3.0), jitter=0.004, seed=seed)
+    pos[:len(blk)] = blk                      # co-moving, under pressure
+    odd = rng.choice(np.arange(len(blk), n), 3000, replace=False)
+    vel[odd] = rng.uniform(-1, 1, (len(odd), 3)).astype(np.float32)
+    vel[odd[0]] = 0.0
+    # the last particle in sorted order sets the reference velocity: keep it a cloud particle
+    pos[-1] = (5.99, 5.99, 5.99)
+    return pos, vel
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_zero_pair_filter_mixed_quiet_and_active_rows(seed):
+    pos, vel = co_moving_mixture(seed)
+    sim, ref = make_pair(len(pos), False, "list", pos=pos, vel=vel)
+    for k in range(1, 7):
+        sim.simulate()
+        ref.step()
+        compare_state(sim, ref, f"co-moving mixture, step {k}")
+    sim.close()
+
+
+def test_zero_pair_filter_on_equals_off(monkeypatch):
+    """SPH_ZERO_PAIR_FILTER=0 evaluates every recorded hit; the default drops the exact-zero
+    pairs.  Same bits, and the counters show the filter actually dropped something."""
+    pos, vel = co_moving_mixture(3)
+    s = sph.default_settings(len(pos), False)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SPH_ZERO_PAIR_FILTER", mode)
+        sim = sph.Simulator(s, flags=_lib.SPH_FLAG_COUNT_PAIRS)
+        sim.upload_state(pos, vel)
+        for _ in range(4):
+            sim.simulate()
+        out[mode] = (sim.download_state(), sim.kernel_times().pair_hits, sim.debug_counters()[15])
+        sim.close()
+    for k in ("pos", "vel", "rho"):
+        assert_bit_equal(out["1"][0][k], out["0"][0][k], f"filter on vs off: {k}")
+    assert out["0"][1] == out["0"][2] == out["1"][2], "hits recorded do not depend on the filter"
+    assert 0 < out["1"][1] < 0.6 * out["0"][1], "the filter dropped the co-moving cloud's pairs"
+
+
+def test_zero_pair_filter_free_fall_drops_every_pair():
+    """The reference's -i random start: everything at rest, no pressure -> every pair is an exact
+    zero and the force sweep evaluates no pair body at all; results still equal the oracle's."""
+    n = 100000
+    s = sph.default_settings(n, True)
+    sim = sph.Simulator(s, flags=_lib.SPH_FLAG_COUNT_PAIRS)
+    ref = O.OracleSim(n, True)
+    sim.setup(); ref.setup()
+    for _ in range(3):
+        sim.simulate(); ref.step()
+    assert sim.kernel_times().pair_hits == 0 and sim.debug_counters()[15] > 0
+    compare_state(sim, ref, "free fall")
+    sim.close()

@@ -175,6 +175,50 @@ def test_reference_initialiser_and_recut(sweep, transport):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["loopback", "streams"])
+def test_get_position_right_after_a_recut_step(transport):
+    """getPosition() after a step that ended with a re-cut (step % recut_every == 0): the re-cut
+    re-uploads every slab through the pinned read-back buffer, so the rows must be fetched
+    again (this used to return the previous frame, or zeros)."""
+    n, world = 80000, 4
+    pos, vel = moving_state(n, 7)
+    settings = sph.default_settings(n, False)
+    mg = M.MultiGpuSimulator(settings, world=world, transport=transport, recut_every=3)
+    mg.upload_state(pos, vel)
+    sim = sph.Simulator(settings)
+    sim.upload_state(pos, vel)
+    for step in range(1, 8):
+        mg.simulate()
+        sim.simulate()
+        assert_bit_equal(np.array(mg.getPosition()), np.array(sim.getPosition()), f"getPosition() after step {step}")
+    sim.close()
+    mg.close()
+
+
+@pytest.mark.gpu
+def test_fresh_state_after_a_failed_step():
+    """A step that fails (here: a particle hops across a whole slab) leaves the driver mid-step;
+    upload_state()/setup() must make it usable again (the phase counter stayed stuck)."""
+    n, world = 60000, 4
+    pos, vel = moving_state(n, 3, vz=0.0)
+    bad = vel.copy()
+    bad[:, 2] = 400.0    # 40 cells per step: far beyond the one-layer halo
+    settings = sph.default_settings(n, False)
+    mg = M.MultiGpuSimulator(settings, world=world, transport="loopback")
+    mg.upload_state(pos, bad)
+    with pytest.raises(sph.SphError):
+        for _ in range(3):
+            mg.simulate()
+        mg.sync()
+    want, want_pos = single_domain(settings, pos, vel, 4)
+    mg.upload_state(pos, vel)
+    for _ in range(4):
+        mg.simulate()
+    assert_bit_equal(mg.download_state()["pos"], want["pos"], "pos after recovery")
+    mg.close()
+
+
+@pytest.mark.gpu
 def test_sinking_fluid_recut_moves_the_cuts():
     """Mass that drifts along z makes the static cuts lopsided; the re-cut follows it."""
     n, world = 60000, 4

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import cudafluidsimulator_amd as sph
-from cudafluidsimulator_amd import slab as S
+import slab_rehearsal as S
 from helpers import assert_bit_equal
 from oracle import oracle as O
 from slab_backend_oracle import OracleSlabBackend
