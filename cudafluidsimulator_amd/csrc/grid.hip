@@ -60,6 +60,27 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     // riders of this launch (each was a launch of its own): the hit-stream pool's allocation
     // cursors are cleared for the density sweep that follows ...
     if (i < X.cursorWords) X.cursor[i] = 0ull;
+    // ... the force sweep's zero-pair filter gets its reference velocity: the most common one among
+    // 256 rows sampled evenly from the (unsorted) input -- a body of fluid in free fall shares one
+    // velocity bit for bit; any choice is correct, a popular one drops the most pairs ...
+    if (X.vref && blockIdx.x == 0) {
+        __shared__ float4 smp[256];
+        __shared__ int best;
+        const int t = threadIdx.x;
+        const float4 v = vel_in[(long long)t * n / 256];
+        smp[t] = v;
+        if (t == 0) best = 0;
+        __syncthreads();
+        int cnt = 0;
+        for (int k = 0; k < 256; ++k) {
+            const float4 w = smp[k];
+            cnt += (w.x == v.x && w.y == v.y && w.z == v.z) ? 1 : 0;
+        }
+        const int rank = cnt * 256 + (255 - t); // most matches, then the lowest sample
+        atomicMax(&best, rank);
+        __syncthreads();
+        if (best == rank) *X.vref = v;
+    }
     bool valid = i < n;
     uint32_t k = valid ? skeys[i] : 0xFFFFFFFFu;
     uint32_t kprev = __shfl_up(k, 1);
@@ -333,8 +354,10 @@ void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr,
 // (int)((float)t*h/h).  Velocities are edited in the sorted stream through the
 // cell table of the last grid build (the reference also uses the
 // pre-integration grid here).
+// zlo/zhi: only threads whose z-layer lies in [zlo, zhi) act (a slab applies the impulse to
+// the layers it owns; one domain: 0, D).
 __global__ void k_click(DevParams P, const int2 *__restrict__ cellRange,
-                        float4 *__restrict__ vel4, int mx, int my) {
+                        float4 *__restrict__ vel4, int mx, int my, int zlo, int zhi) {
     float x = ((float)(mx - SPH_BOX_MIN_X) / (float)(SPH_BOX_MAX_X - SPH_BOX_MIN_X)) *
               P.boxDim;
     float y = ((float)(my - SPH_BOX_MIN_Y) / (float)(SPH_BOX_MAX_Y - SPH_BOX_MIN_Y)) *
@@ -344,7 +367,7 @@ __global__ void k_click(DevParams P, const int2 *__restrict__ cellRange,
     int cy = (int)(y / P.h);
     int cz = (int)(z / P.h);
     cy = (int)((float)P.D - (float)cy);
-    if (cz < 0 || cz >= P.D) return;
+    if (cz < 0 || cz >= P.D || cz < zlo || cz >= zhi) return;
     for (int dy = -2; dy < 3; dy++) {
         int sy = cy + dy;
         if (sy < 0 || sy >= P.D) continue;
@@ -364,6 +387,6 @@ __global__ void k_click(DevParams P, const int2 *__restrict__ cellRange,
 }
 
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4, int mx,
-                      int my, hipStream_t s) {
-    k_click<<<1, P.D, 0, s>>>(P, cellRange, vel4, mx, my);
+                      int my, hipStream_t s, int zlo, int zhi) {
+    k_click<<<1, P.D, 0, s>>>(P, cellRange, vel4, mx, my, zlo, zhi);
 }

@@ -132,6 +132,8 @@ struct sph_mgpu {
     std::chrono::steady_clock::time_point t_begin;
     bool overflow = false;
     int phase = 0;                 // phases of the current step already done (0..3)
+    bool clickQueued = false;      // sph_mgpu_queue_click: applied by the step that completes next
+    int clickX = 0, clickY = 0;
     std::mutex errMu;              // fail() from worker threads
     Workers *workers = nullptr;    // SPH_MGPU_THREADS=1
 };
@@ -643,6 +645,7 @@ int upload_common(sph_mgpu *m, const float *pos, const float *vel, int n) {
     }
     m->phase = 0; // a fresh state also clears whatever a failed step left half-done
     m->overflow = false;
+    m->clickQueued = false;
     int rc = distribute(m, p4, v4);
     if (rc) return rc;
     m->ready = true;
@@ -1054,10 +1057,13 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
             HIPM(m, hipStreamWaitEvent(sl.s, sl.evBnd, 0));
         }
         }
-        if (times) HIPM(m, hipEventRecord(sl.evT[2], sl.s));
         sl.cur = sl.sbuf ^ 1;
         sl.off = sl.i0;
         sl.n_own = sl.i1 - sl.i0;
+        // the click impulse of Simulator::simulate (simulator.cu:482-489) on the layers this slab owns:
+        // new velocities, this step's (pre-integration) grid -- every row of an owned layer is an owned row
+        if (m->clickQueued) SPHM(m, sl, sph_slab_apply_click(sl.h, sl.cur, m->clickX, m->clickY, sl.zlo, sl.zhi));
+        if (times) HIPM(m, hipEventRecord(sl.evT[2], sl.s));
         // ---- 6. position read-back of the owned rows (simulator.cu:479-480), off the compute stream
         HIPM(m, hipEventRecord(sl.evForce, sl.s));
         HIPM(m, hipStreamWaitEvent(sl.copy, sl.evForce, 0));
@@ -1071,6 +1077,7 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
         return SPH_OK;
     });
     if (rcl) return rcl;
+    m->clickQueued = false;
     m->hostPosValid = false;
     m->step++;
     m->stats.steps++;
@@ -1121,6 +1128,16 @@ int sph_mgpu_step(sph_mgpu *m, SphTimes *times) {
         int rc = sph_mgpu_step_phase(m, ph, times);
         if (rc) return rc;
     }
+    return SPH_OK;
+}
+
+int sph_mgpu_queue_click(sph_mgpu *m, int mouse_x, int mouse_y) {
+    if (!m) return SPH_EINVAL;
+    if (m->opt.sweep == SPH_SWEEP_LINKED) return fail(m, SPH_ESTATE, "the click impulse is not available with SPH_SWEEP_LINKED");
+    if (m->phase != 0) return fail(m, SPH_ESTATE, "queue the click between steps");
+    m->clickQueued = true;
+    m->clickX = mouse_x;
+    m->clickY = mouse_y;
     return SPH_OK;
 }
 

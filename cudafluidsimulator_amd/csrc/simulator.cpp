@@ -101,7 +101,8 @@ const float3 *Simulator::getPosition() {
 }
 
 void Simulator::simulate() {
-    if (multi) { // (the click impulse is single-GPU only)
+    if (multi) { // every slab applies the impulse to the layers it owns, after its force sweep
+        if (mouseClicked) mcheck(multi, sph_mgpu_queue_click(multi, clickCoords.x, clickCoords.y), "sph_mgpu_queue_click");
         mcheck(multi, sph_mgpu_step(multi, NULL), "sph_mgpu_step");
         mouseClicked = false;
         return;
@@ -122,6 +123,10 @@ void Simulator::simulateAndTime(Times *times) {
 }
 
 void Simulator::moveParticles(int2 mouse_pos) {
+    if (multi) { // multi-GPU: the impulse needs the slabs' grids of a step: it rides on the next simulate()
+        mcheck(multi, sph_mgpu_queue_click(multi, mouse_pos.x, mouse_pos.y), "sph_mgpu_queue_click");
+        return;
+    }
     if (!impl) return;
     check(impl, sph_apply_click(impl, mouse_pos.x, mouse_pos.y), "sph_apply_click");
 }

@@ -93,6 +93,7 @@ struct sph_handle {
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
+    float4 *quietVref = nullptr;     // ... and its reference velocity (device; written by the gather launch)
     bool useQuiet = true;            // SPH_ZERO_PAIR_FILTER=0 switches the filter off (A/B; same results)
     uint64_t hitsRecorded = 0;       // SPH_FLAG_COUNT_PAIRS: hits in the stream, before the filter
     unsigned long long *maskCursor = nullptr;
@@ -165,6 +166,15 @@ void fill_params(sph_handle *h) {
     P.cut2 = force_cut2(s.h);
     P.D = (int)s.numCellsPerDim;
     P.morton = h->opt.key_order == SPH_KEY_MORTON ? 1 : 0;
+    {
+        // The pair body's short divide / square-root chains are proven for the reference's constants
+        // only (sweep_common.h): any other h or kernel coefficient selects the full IEEE expansions.
+        // SPH_SLIM_DIV=0 forces the full expansions (A/B; same bits).
+        SphSettings ref{};
+        sph_default_settings(&ref, s.numParticles, s.randomInit);
+        P.slimDiv = (s.h == ref.h && s.v_kernel_coeff == ref.v_kernel_coeff && s.d_kernel_coeff == ref.d_kernel_coeff) ? 1 : 0;
+        if (const char *e = getenv("SPH_SLIM_DIV")) if (atoi(e) == 0) P.slimDiv = 0;
+    }
     if (P.morton) {
         int b = 0;
         while ((1 << b) < P.D) ++b;
@@ -303,6 +313,8 @@ int alloc_device(sph_handle *h) {
         const size_t quietWords = 2 * ((cap + 63) / 64) + 2;
         HIPCHK(h, hipMalloc(&h->quiet, quietWords * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->quiet, 0, quietWords * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->quietVref, sizeof(float4)));
+        HIPCHK(h, hipMemset(h->quietVref, 0, sizeof(float4)));
         if (const char *e = getenv("SPH_ZERO_PAIR_FILTER")) h->useQuiet = atoi(e) != 0;
     }
     HIPCHK(h, hipMalloc(&h->boundsDev, 16 * sizeof(int)));
@@ -482,6 +494,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.pv8 = h->pv8;
     // single domain only: a slab's owned range starts anywhere and its halo densities arrive later
     A.quiet = (h->useQuiet && !h->external && h->n > 0) ? h->quiet : nullptr;
+    A.quietVref = h->quietVref;
     A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
     A.listNext = reinterpret_cast<const int *>(h->ws.vals[0]);
@@ -496,6 +509,7 @@ GatherExtras gather_extras(sph_handle *h) {
         X.cursorWords = (int)(kCursorBytes / sizeof(unsigned long long));
         h->cursorClean = true;
     }
+    if (h->quiet && h->useQuiet && !h->external && h->n > 0) X.vref = h->quietVref;
     return X;
 }
 
@@ -754,6 +768,20 @@ int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_al
     return SPH_OK;
 }
 
+int sph_slab_apply_click(sph_handle *h, int buf, int mx, int my, int z_lo, int z_hi) {
+    if (!h) return SPH_EINVAL;
+    SPH_ON_DEVICE(h);
+    if (!h->external || !h->pos4[0]) return fail(h, SPH_ESTATE, "sph_bind_buffers first");
+    if (buf != 0 && buf != 1) return fail(h, SPH_EINVAL, "bad buffer index");
+    if (h->opt.sweep == SPH_SWEEP_LINKED)
+        return fail(h, SPH_ESTATE, "the click impulse is not available with SPH_SWEEP_LINKED");
+    if (!h->gridValid || h->sorted != (buf ^ 1))
+        return fail(h, SPH_ESTATE, "click needs a completed slab step (it reuses that step's grid)");
+    sph_launch_click(h->P, h->cellRange, h->vel4[buf], mx, my, h->compute, z_lo, z_hi);
+    HIPCHK(h, hipGetLastError());
+    return SPH_OK;
+}
+
 int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, int a1, int b1,
                           int n_all, int last, void *hip_stream) {
     if (!h) return SPH_EINVAL;
@@ -953,6 +981,7 @@ void sph_destroy(sph_handle *h) {
     if (h->maskOff) (void)hipFree(h->maskOff);
     if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->quiet) (void)hipFree(h->quiet);
+    if (h->quietVref) (void)hipFree(h->quietVref);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
     if (h->partTiles) (void)hipFree(h->partTiles);
     if (h->boundsHost) (void)hipHostFree(h->boundsHost);

@@ -36,6 +36,8 @@ struct DevParams {
     int D;         // cells per dimension (numCellsPerDim as int)
     int numCells;  // entries of the cell table: D^3 (flattened keys) or 8^ceil(log2 D) (Morton)
     int morton;    // key function: 0 = flattened cell index (simulator.cu:78-82), 1 = Morton
+    int slimDiv;   // 1: h and the kernel coefficients are the reference's (main.cpp:57-63): the pair body may use
+                   // the divide / square-root chains without range fix-ups (sweep_common.h); 0: full IEEE expansions
 };
 
 // The neighbour grid's key function.  Flattened = the reference's x + y D + z D^2; Morton =
@@ -91,6 +93,7 @@ struct GatherExtras {
     unsigned long long *cursor = nullptr; // hit-stream allocation cursors to clear ...
     int cursorWords = 0;                  // ... this many 8-byte words
     int *bounds = nullptr;                // slab path: bounds[t] = #keys < thr.v[t], bounds[nthr] = n
+    float4 *vref = nullptr;               // zero-pair filter: the most common velocity among 256 sampled rows goes here
     Thresholds thr{};
     int nthr = 0;
 };
@@ -118,7 +121,7 @@ struct SegmentTable {
 };
 void sph_launch_copy_segments(const SegmentTable &T, float4 *dpos, float4 *dvel, hipStream_t s);
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4,
-                      int mx, int my, hipStream_t s);
+                      int mx, int my, hipStream_t s, int zlo = 0, int zhi = 1 << 30);
 
 // Hit-stream pool of the list sweep: cut into sub-pools with one allocation cursor each
 // (one cursor per 256 bytes), see k_density_mask_lds.
@@ -154,8 +157,9 @@ struct SweepArgs {
     unsigned long long maskCapacity;  // pool size in quads
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
     uint32_t *quiet;                  // zero-pair filter (may be null = off): bit j of this array is set when sorted row j
-                                      // has no pressure and moves with the reference velocity (the last sorted row's); a
-                                      // hit between two such rows adds exactly +-0 to the force and is dropped unread
+                                      // has no pressure and moves with the reference velocity *quietVref; a hit between
+                                      // two such rows adds exactly +-0 to the force and is dropped unread
+    const float4 *quietVref;          // the reference velocity (picked by the gather launch of this step's grid build)
     int rhoToVel4;                    // list sweep: also store rho in vel4.w (slab halo exchange B)
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
     const int *listHead;              // [numCells] first particle of the cell or -1

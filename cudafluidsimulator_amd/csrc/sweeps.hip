@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_direct(DevParams P, SweepA
                     if (x < 0 || x >= P.D || y < 0 || y >= P.D || z < 0 || z >= P.D) continue;
                     const int2 r = A.cellRange[sph_cell_key(P, x, y, z)];
                     for (int j = r.x; j < r.y; ++j)
-                        force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+                        force_pair<false>(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
                 }
     } else {
         int js[9], je[9];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_direct(DevParams P, SweepA
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             for (int j = js[r]; j < je[r]; ++j)
-                force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j],
+                force_pair<false>(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j],
                            F);
         }
     }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_density_lds(DevParams P, SweepAr
 #define SW_PUSH_BRANCHFREE 1 // measured: force sweep 2.47 ms vs 2.55 ms (n = 4,194,304)
 #endif
 
-template <bool FAST>
+template <bool FAST, bool SLIM>
 struct ForceVisitor {
     const DevParams &P;
     const SweepArgs &A;
@@ -392,7 +392,7 @@ struct ForceVisitor {
 #pragma unroll
         for (int u = 0; u < SW_DRAIN; ++u) {
             if (FAST) force_pair_fast(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
-            else force_pair(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
+            else force_pair<SLIM>(P, pix, piy, piz, vix, viy, viz, prs_i, pj[u], vj[u], F);
         }
     }
     __device__ __forceinline__ void poll() {
@@ -404,7 +404,7 @@ struct ForceVisitor {
     }
 };
 
-template <bool FAST>
+template <bool FAST, bool SLIM>
 __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs A) {
     __shared__ float4 stageAll[SW_WAVES][SW_CAP + SW_UNROLL];
     __shared__ uint32_t queueAll[SW_WAVES][SW_QCAP * SPH_WAVE];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_lds(DevParams P, SweepArgs
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
     int js[9], je[9];
     load_runs(P, A.cellRange, c, valid, js, je);
-    ForceVisitor<FAST> V{P, A, queueAll[w], lane, (uint32_t)iSafe, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
+    ForceVisitor<FAST, SLIM> V{P, A, queueAll[w], lane, (uint32_t)iSafe, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z,
                    fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY)),
                    0u, 0u, {0.f, 0.f, 0.f}};
     WalkStamps W;
@@ -485,7 +485,9 @@ void sph_launch_force(const DevParams &P, const SweepArgs &A, int mathMode, int 
     else if (sweep == 1)
         k_force_direct<<<blocks, SW_THREADS, 0, s>>>(P, A); // strict only (check path)
     else if (mathMode == 1)
-        k_force_lds<true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_lds<true, true><<<blocks, SW_THREADS, 0, s>>>(P, A);
+    else if (P.slimDiv)
+        k_force_lds<false, true><<<blocks, SW_THREADS, 0, s>>>(P, A);
     else
-        k_force_lds<false><<<blocks, SW_THREADS, 0, s>>>(P, A);
+        k_force_lds<false, false><<<blocks, SW_THREADS, 0, s>>>(P, A);
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(LK_THREADS) void k_force_linked(DevParams P, SweepA
         for (int y = max(c.y - 1, 0); y <= min(c.y + 1, P.D - 1); ++y)
             for (int x = max(c.x - 1, 0); x <= min(c.x + 1, P.D - 1); ++x)
                 for (int j = A.listHead[x + y * P.D + z * P.D * P.D]; j >= 0; j = A.listNext[j])
-                    force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
+                    force_pair<false>(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pos4[j], A.vel4[j], F);
     float vx = vi.x, vy = vi.y, vz = vi.z;
     integrate_particle(P, pi, vx, vy, vz, F, vi.w);
     store_particle(A, i, pi, vx, vy, vz, vi.w, F);

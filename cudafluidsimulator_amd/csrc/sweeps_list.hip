@@ -102,16 +102,18 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 // reading j at all.  That is every pair of a body of fluid in free fall -- all of the
 // reference's `-i random` run until the cloud reaches the floor, and the part of it still
 // falling afterwards.  The density sweep leaves one bit per sorted row: "no pressure, and the
-// velocity equals the last sorted row's" (any reference velocity is correct; the last row sits
-// at the top of the highest z-layer, the last place gravity empties); the force sweep of a
-// quiet row clears the quiet candidates out of its hit masks, 32 at a time.
+// velocity equals the reference velocity" (any reference is correct; the gather launch picks the
+// most common velocity among 256 sampled rows -- the last sorted row, the top of the highest
+// z-layer, was the first choice and went wrong at step 57 of the headline run, when splashes from
+// the floor opened a z-layer of their own); the force sweep of a quiet row clears the quiet
+// candidates out of its hit masks, 32 at a time.
 __device__ __forceinline__ bool sl_is_quiet(float rho, const float4 &v, const float4 &vref) {
     const float prs = fmaxf(0.f, SPH_GAS_CONSTANT * (rho - SPH_REST_DENSITY));
     return prs == 0.f && v.x == vref.x && v.y == vref.y && v.z == vref.z;
 }
 // one 64-bit word per 64-row wave (rows [i - lane, i - lane + 64), i - lane a multiple of 64)
 __device__ __forceinline__ void sl_store_quiet(const SweepArgs &A, int i, bool valid, float rho, int lane) {
-    const float4 vref = A.pv8[2 * (size_t)(A.n_all - 1) + 1];
+    const float4 vref = *A.quietVref;
     bool q = false;
     if (valid) q = sl_is_quiet(rho, A.pv8[2 * (size_t)i + 1], vref);
     const unsigned long long qb = __ballot(q);
@@ -440,7 +442,7 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
 #ifndef SL_K2_WAVES
 #define SL_K2_WAVES 0 // >0: ask for that many resident waves per SIMD (caps the VGPR budget)
 #endif
-template <bool FAST>
+template <bool FAST, bool SLIM>
 __global__
 #if SL_K2_WAVES
 __launch_bounds__(SL_K2_THREADS, SL_K2_WAVES)
@@ -481,12 +483,6 @@ void k_force_list(DevParams P, SweepArgs A) {
     const int tile0 = A.i_origin + tileIdx * blockDim.x + (threadIdx.x & ~63);
     const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
-    {
-        const int lane = threadIdx.x & 63;
-        for (int k = lane; k < 2 * wlen; k += SPH_WAVE) win[k] = A.pv8[2 * (size_t)w0 + k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
 #endif
 
     // A wave that found the mask pool exhausted has no stream: its particles are
@@ -531,6 +527,17 @@ void k_force_list(DevParams P, SweepArgs A) {
             }
         };
         fetch();
+        // A wave whose lanes have nothing left after the filter (fluid in free fall) skips the sweep:
+        // no window, no gathers, straight to the integration.
+        if (__ballot(mq[0] != 0u)) {
+#if SL_WINDOW
+        {
+            const int lane = threadIdx.x & 63;
+            for (int k = lane; k < 2 * wlen; k += SPH_WAVE) win[k] = A.pv8[2 * (size_t)w0 + k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#endif
         auto pop = [&]() -> int {
             if (m == 0) { // next pair; queued masks are never 0, so mq[0] == 0 means "queue empty"
                 m = mq[0];
@@ -548,7 +555,7 @@ void k_force_list(DevParams P, SweepArgs A) {
         };
         auto body = [&](const float4 &pj, const float4 &vj) {
             if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
-            else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
+            else force_pair<SLIM>(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
         };
         // Two gathers are always in flight while a pair body is evaluated: the
         // loop is unrolled by two so the pipeline registers never move.  (Three in
@@ -615,6 +622,7 @@ void k_force_list(DevParams P, SweepArgs A) {
             if (!__ballot(live)) { SL_USE(j0, p0, v0) SL_FETCH(j1, p1, v1) SL_USE(j1, p1, v1) break; }
             SL_FETCH(j1, p1, v1)
         }
+        }
 #undef SL_FETCH
 #undef SL_USE
     }
@@ -674,7 +682,7 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
 // Particles whose wave found the mask pool exhausted in the density sweep: test
 // every candidate, like the check path.  Launched after k_force_list every step;
 // waves with nothing to do leave after one load.
-template <bool FAST>
+template <bool FAST, bool SLIM>
 __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, SweepArgs A) {
     // one launch over the hull of the (up to two) row ranges of the force launch
     const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, Swee
     for (int r = 0; r < 9; ++r)
         for (int j = js[r]; j < je[r]; ++j) {
             if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pv8[2 * (size_t)j], A.pv8[2 * (size_t)j + 1], F);
-            else force_pair(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pv8[2 * (size_t)j], A.pv8[2 * (size_t)j + 1], F);
+            else force_pair<SLIM>(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, A.pv8[2 * (size_t)j], A.pv8[2 * (size_t)j + 1], F);
         }
     if (mine) {
         float vx = vi.x, vy = vi.y, vz = vi.z;
@@ -740,10 +748,13 @@ void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode,
     const int hullEnd = B.i_end2 > B.i_begin2 ? B.i_end2 : B.i_end;
     const int blocks = (hullEnd - B.i_begin + SW_THREADS - 1) / SW_THREADS;
     if (mathMode == 1) {
-        k_force_list<true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
-        k_force_fallback<true><<<blocks, SW_THREADS, 0, s>>>(P, B);
+        k_force_list<true, true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        k_force_fallback<true, true><<<blocks, SW_THREADS, 0, s>>>(P, B);
+    } else if (P.slimDiv) { // the reference's h and kernel coefficients (sweep_common.h)
+        k_force_list<false, true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        k_force_fallback<false, true><<<blocks, SW_THREADS, 0, s>>>(P, B);
     } else {
-        k_force_list<false><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
-        k_force_fallback<false><<<blocks, SW_THREADS, 0, s>>>(P, B);
+        k_force_list<false, false><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        k_force_fallback<false, false><<<blocks, SW_THREADS, 0, s>>>(P, B);
     }
 }

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "sph_mgpu_unique_id", "sph_mgpu_create", "sph_mgpu_destroy", "sph_mgpu_setup",
     "sph_mgpu_upload_state", "sph_mgpu_step", "sph_mgpu_step_phase", "sph_mgpu_positions_host",
     "sph_mgpu_download_state",
-    "sph_mgpu_sync", "sph_mgpu_get_stats", "sph_mgpu_last_error",
+    "sph_mgpu_sync", "sph_mgpu_get_stats", "sph_mgpu_last_error", "sph_mgpu_queue_click",
 ]
 
 
@@ -76,6 +76,7 @@ def load_mgpu_library():
     L.sph_mgpu_positions_host.restype = fp
     L.sph_mgpu_download_state.argtypes = [hp, fp, fp, fp, C.POINTER(C.c_int)]
     L.sph_mgpu_sync.argtypes = [hp]
+    L.sph_mgpu_queue_click.argtypes = [hp, C.c_int, C.c_int]
     L.sph_mgpu_get_stats.argtypes = [hp, C.POINTER(SphMgpuStats), C.c_int]
     L.sph_mgpu_last_error.argtypes = [hp]
     L.sph_mgpu_last_error.restype = C.c_char_p
@@ -122,6 +123,8 @@ class MultiGpuSimulator:
         if rc:
             self._h = C.c_void_p()
             raise SphError(f"sph_mgpu_create failed ({rc}): {self._L.sph_mgpu_last_error(None).decode()}")
+        self.mouseClicked = False
+        self.clickCoords = (0, 0)
 
     def _check(self, rc, what):
         if rc:
@@ -151,6 +154,10 @@ class MultiGpuSimulator:
         self._check(self._L.sph_mgpu_upload_state(self._h, _fp(pos), _fp(vel), len(pos)), "sph_mgpu_upload_state")
 
     def simulate(self):
+        if self.mouseClicked:  # simulator.cu:482-489: applied after this step's force sweep
+            self._check(self._L.sph_mgpu_queue_click(self._h, int(self.clickCoords[0]), int(self.clickCoords[1])),
+                        "sph_mgpu_queue_click")
+            self.mouseClicked = False
         self._check(self._L.sph_mgpu_step(self._h, None), "sph_mgpu_step")
 
     def step_phase(self, phase, times=None):
@@ -159,6 +166,11 @@ class MultiGpuSimulator:
 
     def simulateAndTime(self, times):
         self._check(self._L.sph_mgpu_step(self._h, C.byref(times)), "sph_mgpu_step")
+
+    def moveParticles(self, mouse_pos):
+        """Rides on the next simulate(): the impulse needs the slabs' grids of a step."""
+        self._check(self._L.sph_mgpu_queue_click(self._h, int(mouse_pos[0]), int(mouse_pos[1])),
+                    "sph_mgpu_queue_click")
 
     def getPosition(self):
         p = self._L.sph_mgpu_positions_host(self._h)

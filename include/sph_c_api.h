@@ -249,6 +249,11 @@ int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int cou
 int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
                         const uint32_t *thresholds, int nthr, void *bounds_dev_out);
 int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all, void *hip_stream);
+/* kernelMoveParticles (simulator.cu:329-367) for one slab: the impulse of sph_apply_click on the
+ * z-layers [z_lo, z_hi) this slab owns, applied to the NEW state (buffer `buf`: the rows the last
+ * sph_slab_force* launch wrote, still in that step's sorted order) through the cell table of that
+ * step's sort -- the pre-integration grid, like the reference (simulator.cu:482-489). */
+int sph_slab_apply_click(sph_handle *h, int buf, int mouse_x, int mouse_y, int z_lo, int z_hi);
 /* rows [a0, b0) and [a1, b1) (either may be empty; a1 >= b0) of the owned range, in ONE
  * launch; hip_stream NULL = the handle's stream. */
 int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, int a1, int b1,

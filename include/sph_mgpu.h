@@ -103,6 +103,11 @@ int sph_mgpu_setup(sph_mgpu *m);
 int sph_mgpu_upload_state(sph_mgpu *m, const float *pos_xyz, const float *vel_xyz, int n);
 /* Simulator::simulate / simulateAndTime (simulator.cu:462-546) over all local slabs. */
 int sph_mgpu_step(sph_mgpu *m, SphTimes *times);
+/* `mouseClicked` of Simulator::simulate (simulator.cu:482-489): the NEXT step that completes
+ * applies kernelMoveParticles (simulator.cu:329-367) after its force sweep, every slab on the
+ * z-layers it owns, through that step's grid.  One process per GPU: every rank queues the same
+ * click.  Queue it between steps. */
+int sph_mgpu_queue_click(sph_mgpu *m, int mouse_x, int mouse_y);
 /* The four phases of a step on their own (1: partition + exchange A, 2: headers + host sync,
  * 3: assemble/sort/density + exchange B, 4: force + read-back), in this order. */
 int sph_mgpu_step_phase(sph_mgpu *m, int phase, SphTimes *times);

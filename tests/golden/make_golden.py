@@ -7,6 +7,7 @@ only: inputs are regenerated from seeds / the reference initialisers.
 Run:  python tests/golden/make_golden.py          (the small array fixtures)
       python tests/golden/make_golden.py --full   (sha256 of the n = 4,194,304 run)
       python tests/golden/make_golden.py --config4 | --config5   (first steps of configs 4 / 5 at full size)
+      python tests/golden/make_golden.py --morton  (Morton-keyed oracle, n = 4,194,304, moving state, steps 1 and 3)
 """
 import os
 import sys
@@ -87,6 +88,47 @@ def full_size_checksums(n=4194304, checkpoints=(1, 10, 30, 50, 60, 80, 100), dum
     with open(os.path.join(HERE, f"random{n}_sha256.json"), "w") as f:
         json.dump(out, f, indent=1)
 
+def morton_state(n=4194304, seed=20):
+    """Input of the Morton fixture: the reference's -i random positions with seeded random velocities
+    (up to 0.3 cells per step along every axis).  The reference's own start -- everything at rest --
+    falls as one body for 45 steps: cells only exchange particles along y, and then the Morton and
+    the flattened key put every cell's particles in the SAME order; with migration along all three
+    axes they do not."""
+    sim = O.OracleSim(n, True)
+    sim.setup()
+    pos = sim.download()["pos"].copy()
+    sim.close()
+    vel = np.random.default_rng(seed).uniform(-3.0, 3.0, (n, 3)).astype(np.float32)
+    return pos, vel
+
+
+def morton_checksums(n=4194304, checkpoints=(1, 3)):
+    """BASELINE config 3 names the Morton ordering: the oracle with its key function switched to
+    Morton (oracle_set_key_order) on morton_state(), sha256 after steps 1 and 3."""
+    import hashlib
+    import json
+    pos, vel = morton_state(n)
+    out = {"n": n, "init": "random positions + seeded velocities (make_golden.morton_state)", "seed": 20,
+           "order": "particle id", "dtype": "<f4", "steps": {}, "flattened_steps": {}}
+    for ko in ("morton", "flattened"):
+        O.set_key_order(ko)
+        sim = O.OracleSim(n, True)
+        sim.upload(pos, vel)
+        done = 0
+        for k in checkpoints:
+            sim.step(k - done)
+            done = k
+            d = sim.download()
+            out["steps" if ko == "morton" else "flattened_steps"][str(k)] = {
+                "pos_sha256": hashlib.sha256(np.ascontiguousarray(d["pos"]).tobytes()).hexdigest(),
+                "rho_sha256": hashlib.sha256(np.ascontiguousarray(d["rho"]).tobytes()).hexdigest()}
+            print(ko, n, k, flush=True)
+        sim.close()
+    O.set_key_order("flattened")
+    with open(os.path.join(HERE, f"random{n}_morton_sha256.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def big_config_checksums(n, random_init, checkpoints):
     """BASELINE configs 4 (-n 16777216 -i random) and 5 (-n 67108864 -i grid, the dense-lattice
     extension): sha256 of the oracle's arrays after the first step(s) at FULL size.  Config 5 is
@@ -112,6 +154,9 @@ def big_config_checksums(n, random_init, checkpoints):
 
 
 if __name__ == "__main__":
+    if "--morton" in sys.argv:
+        morton_checksums()
+        sys.exit(0)
     if "--config4" in sys.argv:
         big_config_checksums(16777216, True, (1, 2))
         sys.exit(0)

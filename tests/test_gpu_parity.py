@@ -506,3 +506,125 @@ def test_zero_pair_filter_free_fall_drops_every_pair():
     assert sim.kernel_times().pair_hits == 0 and sim.debug_counters()[15] > 0
     compare_state(sim, ref, "free fall")
     sim.close()
+
+
+# ---- reachable product paths that had no test ----
+
+@pytest.mark.parametrize("n", [4096, 262144])
+def test_step_graphs_equal_the_oracle(n, monkeypatch):
+    """SPH_GRAPH=1: the three phases of a step replayed as hipGraphs (captured once per
+    read-back slot, sph_api.hip capture_step_graph).  Ten steps, bit-equal to the oracle after
+    every one of them (getPosition() included: the read-back runs beside the replays), and the
+    per-kernel event bookkeeping of the replays still adds up to ten steps."""
+    monkeypatch.setenv("SPH_GRAPH", "1")
+    sim, ref = make_pair(n, True)
+    t = sph.Times()
+    for k in range(1, 11):
+        if k % 2:
+            sim.simulate()
+        else:
+            sim.simulateAndTime(t)
+        ref.step()
+        assert_bit_equal(np.array(sim.getPosition()), ref.download()["pos"], f"graph replay, step {k}: getPosition")
+    compare_state(sim, ref, "graph replay, step 10")
+    kt = sim.kernel_times()
+    assert kt.steps == 10 and kt.density > 0 and kt.force > 0 and t.iters == 5
+    # a new state drops the captured graphs (their launches carry the old tile map)
+    pos, vel = random_state(n, 4)
+    sim.upload_state(pos, vel)
+    ref.upload(pos, vel)
+    for _ in range(3):
+        sim.simulate()
+        ref.step()
+    compare_state(sim, ref, "graph replay after a re-upload")
+    sim.close()
+
+
+@pytest.mark.parametrize("sweep", ["list", "lds"])
+def test_mapped_positions_after_every_step(sweep):
+    """SPH_FLAG_MAPPED_POSITIONS (zero-copy display path): the force sweep
+    scatters the id-ordered positions straight into host-mapped memory; getPosition() after
+    each of five steps equals the oracle's positions, and so does the device state."""
+    n = 50000
+    s = sph.default_settings(n, True)
+    sim = sph.Simulator(s, sweep=sweep, flags=_lib.SPH_FLAG_MAPPED_POSITIONS)
+    ref = O.OracleSim(n, True)
+    sim.setup(); ref.setup()
+    for k in range(1, 6):
+        sim.simulate()
+        ref.step()
+        assert_bit_equal(np.array(sim.getPosition()), ref.download()["pos"], f"mapped: getPosition after step {k}")
+    compare_state(sim, ref, "mapped, step 5")
+    sim.close()
+
+
+# ---- the pair body's short divide / square-root chains are for the reference's constants only ----
+
+def _custom_pair(hh, cells, n, pos, vel, sweep, dt=0.002):
+    import ctypes as C
+    s = sph.default_settings(n, False)
+    s.h = hh
+    s.boxDim = hh * cells
+    s.numCellsPerDim = cells
+    s.timestep = dt
+    h = np.float32(s.h)
+    s.v_kernel_coeff = float(np.float32(45.0) / (np.float32(3.14159265) * np.float32(float(h) ** 6)))
+    s.d_kernel_coeff = float(np.float32(315.0) / (np.float32(64.0) * np.float32(3.14159265) * np.float32(float(h) ** 9)))
+    sim = sph.Simulator(s, sweep=sweep)
+    sim.upload_state(pos, vel)
+    ref = O.OracleSim(n, False)
+    C.memmove(C.byref(ref.settings), C.byref(s), C.sizeof(s))
+    ref.close()
+    ref._h = O.lib().oracle_sim_create(C.byref(ref.settings))
+    ref.upload(pos, vel)
+    return sim, ref
+
+
+@pytest.mark.parametrize("hh", [0.01, 1.0])
+@pytest.mark.parametrize("sweep", SWEEPS)
+def test_extreme_but_legal_settings_use_the_full_ieee_pair_body(sweep, hh):
+    """h = 0.01 and h = 1 (64-cell boxes): kernel coefficients 1e12 / 1e-6 times the reference's,
+    densities from 1e-4 (the clamp) to 1e7, with a dense cluster, exactly coincident particles and
+    pairs 2e-4 apart (just above the EPS gate).  Any h or coefficient other than the reference's
+    selects the compiler's IEEE divide / square root in the pair body (DevParams::slimDiv): list,
+    lds and direct sweeps all equal the oracle bit for bit."""
+    rng = np.random.default_rng(11)
+    cells, n = 64, 6000
+    box = hh * cells
+    pos = rng.uniform(1.5 * hh, box - 1.5 * hh, (n, 3)).astype(np.float32)
+    pos[:1500] = (np.float32(box / 2) + rng.uniform(-0.6 * hh, 0.6 * hh, (1500, 3))).astype(np.float32)  # dense cluster
+    pos[1500:1520] = pos[1520:1540]                                   # coincident pairs
+    pos[1540:1560] = pos[1560:1580] + np.float32(2e-4)                # near-coincident pairs
+    vel = rng.uniform(-20 * hh, 20 * hh, (n, 3)).astype(np.float32)
+    sim, ref = _custom_pair(hh, cells, n, pos, vel, sweep)
+    for k in range(1, 5):
+        sim.simulate(); ref.step()
+        compare_state(sim, ref, f"h={hh} {sweep} step {k}")
+    sim.close()
+
+
+def test_reference_settings_slim_equals_full_ieee(monkeypatch):
+    """With the reference's constants the default pair body (bare Newton chains) and the full IEEE
+    expansions (SPH_SLIM_DIV=0) give the same bits on a state with pressure, coincident and
+    near-coincident particles; so does the check path (direct sweep: always the full expansions)."""
+    pos = dense_block(20, spacing=0.02, jitter=0.004, seed=5)
+    pos[10:20] = pos[30:40]
+    pos[50:60] = pos[70:80] + np.float32(1.2e-4)
+    vel = np.random.default_rng(6).uniform(-2, 2, pos.shape).astype(np.float32)
+    s = sph.default_settings(len(pos), False)
+    out = {}
+    for name, env, sweep in (("slim", None, "list"), ("ieee", "0", "list"), ("direct", None, "direct")):
+        if env is None:
+            monkeypatch.delenv("SPH_SLIM_DIV", raising=False)
+        else:
+            monkeypatch.setenv("SPH_SLIM_DIV", env)
+        sim = sph.Simulator(s, sweep=sweep)
+        sim.upload_state(pos, vel)
+        for _ in range(5):
+            sim.simulate()
+        out[name] = sim.download_state()
+        sim.close()
+    assert out["slim"]["rho"].max() > 2000
+    for k in ("pos", "vel"):
+        assert_bit_equal(out["slim"][k], out["ieee"][k], f"slim vs full IEEE: {k}")
+        assert_bit_equal(out["slim"][k], out["direct"][k], f"list vs direct: {k}")

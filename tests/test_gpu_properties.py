@@ -198,3 +198,33 @@ def test_config5_67108864_matches_the_oracles_checksum():
     assert _sha(st["pos"]) == g["steps"]["1"]["pos_sha256"], "pos @ step 1"
     assert _sha(st["rho"]) == g["steps"]["1"]["rho_sha256"], "rho @ step 1"
     sim.close()
+
+
+def test_morton_order_at_full_size_matches_the_morton_keyed_oracle():
+    """SPH_KEY_MORTON (BASELINE config 3's ordering) at n = 4,194,304 against the oracle run with the
+    Morton key function: sha256 after steps 1 and 3 of a state that migrates along all three axes
+    (tests/golden/make_golden.py --morton; the all-at-rest start does not tell the two key functions
+    apart).  The same input under the flattened key reproduces the flattened oracle's digests, and
+    those differ from the Morton ones at step 3: the key function changes the summation order."""
+    import importlib.util
+    import os
+    g = _golden("random4194304_morton_sha256.json")
+    spec = importlib.util.spec_from_file_location(
+        "make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    n = g["n"]
+    pos, vel = mg.morton_state(n, g["seed"])
+    for ko, want in (("morton", g["steps"]), ("flattened", g["flattened_steps"])):
+        sim = sph.Simulator(sph.default_settings(n, True), sweep="direct" if ko == "morton" else "list", key_order=ko)
+        sim.upload_state(pos, vel)
+        done = 0
+        for k in sorted(int(x) for x in want):
+            for _ in range(k - done):
+                sim.simulate()
+            done = k
+            st = sim.download_state()
+            assert _sha(st["pos"]) == want[str(k)]["pos_sha256"], f"{ko}: pos @ step {k}"
+            assert _sha(st["rho"]) == want[str(k)]["rho_sha256"], f"{ko}: rho @ step {k}"
+        sim.close()
+    assert g["steps"]["3"]["pos_sha256"] != g["flattened_steps"]["3"]["pos_sha256"]

@@ -219,6 +219,37 @@ def test_fresh_state_after_a_failed_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,transport,recut", [(4, "loopback", 0), (3, "streams", 0), (4, "loopback", 2)])
+def test_click_impulse_in_multi_gpu_mode(world, transport, recut):
+    """simulate() with `mouseClicked` set (simulator.cu:482-489) over z-slabs: every slab applies
+    kernelMoveParticles to the layers it owns through that step's grid -- the same particles get the
+    same impulse as in the single domain (the click used to be dropped silently).  With a
+    re-cut at the end of the clicked step the impulse still lands before the state is redistributed."""
+    n = 80000
+    pos, vel = moving_state(n, 9)
+    settings = sph.default_settings(n, False)
+    sim = sph.Simulator(settings)
+    sim.upload_state(pos, vel)
+    mg = M.MultiGpuSimulator(settings, world=world, transport=transport, recut_every=recut)
+    mg.upload_state(pos, vel)
+    clicks = {2: (400, 300), 4: (250, 200), 5: (590, 440)}
+    for step in range(1, 8):
+        if step in clicks:
+            for s in (sim, mg):
+                s.mouseClicked, s.clickCoords = True, clicks[step]
+        sim.simulate()
+        mg.simulate()
+        assert not mg.mouseClicked
+    want, got = sim.download_state(), mg.download_state()
+    plain, _ = single_domain(settings, pos, vel, 7)
+    assert (want["vel"] != plain["vel"]).any(axis=1).sum() > 50, "the clicks moved something"
+    assert_bit_equal(got["vel"], want["vel"], "vel")
+    assert_bit_equal(got["pos"], want["pos"], "pos")
+    sim.close()
+    mg.close()
+
+
+@pytest.mark.gpu
 def test_sinking_fluid_recut_moves_the_cuts():
     """Mass that drifts along z makes the static cuts lopsided; the re-cut follows it."""
     n, world = 60000, 4
