@@ -46,9 +46,10 @@ def parse():
     ap.add_argument("--mode", choices=["time", "free", "display"], default="time",
                     help="time: simulateAndTime loop (-m time); free: simulate() loop; display: "
                          "simulate() + getPosition() every frame like display.cpp:36-37")
-    ap.add_argument("--readback", choices=["copy", "mapped"], default="copy",
+    ap.add_argument("--readback", choices=["copy", "mapped", "none"], default="copy",
                     help="copy: overlapped device->host copy per step (default); mapped: the force sweep "
-                         "writes getPosition()'s buffer in host-mapped memory (zero-copy)")
+                         "writes getPosition()'s buffer in host-mapped memory (zero-copy); none: kernel studies "
+                         "only (SPH_FLAG_NO_READBACK: not the reference's step, never `value`)")
     ap.add_argument("--no-linked-leg", action="store_true",
                     help="skip the secondary run of the reference's linked-list neighbour structure")
     ap.add_argument("--no-fast-leg", action="store_true",
@@ -116,7 +117,7 @@ def timed_run(sph, _lib, torch, s, args, K, W, device, settle=0, sweep=None, mat
     sweep = sweep or args.sweep
     math = math or args.math
     mode = mode or args.mode
-    rb_flag = _lib.SPH_FLAG_MAPPED_POSITIONS if args.readback == "mapped" else 0
+    rb_flag = {"mapped": _lib.SPH_FLAG_MAPPED_POSITIONS, "none": _lib.SPH_FLAG_NO_READBACK}.get(args.readback, 0)
 
     def one_step(sm, tm):
         if mode == "time":

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "sph_set_stream", "sph_bind_buffers", "sph_slab_sort", "sph_slab_partition", "sph_slab_copy_segments", "sph_slab_density",
     "sph_slab_force", "sph_initial_positions", "sph_save_state", "sph_load_state",
     "sph_debug_counters", "sph_get_stream", "sph_slab_partition_async", "sph_slab_sort_async",
-    "sph_slab_patch_halo", "sph_slab_force_ranges", "sph_num_table_cells", "sph_slab_apply_click",
+    "sph_slab_patch_halo", "sph_slab_force_ranges", "sph_num_table_cells", "sph_slab_apply_click", "sph_slab_records",
 ]
 
 

@@ -5,6 +5,8 @@
 // Also the click impulse (kernelMoveParticles, simulator.cu:329-367).
 #include "sph_device.h"
 
+#include <algorithm>
+
 // getGridCell + flattenGridCoord (simulator.cu:57-82).  The division is the
 // IEEE fp32 divide of the reference (hipcc's default `/` is correctly rounded);
 // the flattening is done in integers, which equals the reference's float
@@ -60,26 +62,24 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     // riders of this launch (each was a launch of its own): the hit-stream pool's allocation
     // cursors are cleared for the density sweep that follows ...
     if (i < X.cursorWords) X.cursor[i] = 0ull;
+    if (i < X.quietWords) X.quietClear[i] = 0u;
     // ... the force sweep's zero-pair filter gets its reference velocity: the most common one among
-    // 256 rows sampled evenly from the (unsorted) input -- a body of fluid in free fall shares one
+    // 64 rows sampled evenly from the (unsorted) input -- a body of fluid in free fall shares one
     // velocity bit for bit; any choice is correct, a popular one drops the most pairs ...
-    if (X.vref && blockIdx.x == 0) {
-        __shared__ float4 smp[256];
-        __shared__ int best;
-        const int t = threadIdx.x;
-        const float4 v = vel_in[(long long)t * n / 256];
-        smp[t] = v;
-        if (t == 0) best = 0;
-        __syncthreads();
+    if (X.vref && blockIdx.x == 0 && threadIdx.x < SPH_WAVE) { // one wave, one sample per lane
+        const float4 v = vel_in[(long long)lane * n / SPH_WAVE];
         int cnt = 0;
-        for (int k = 0; k < 256; ++k) {
-            const float4 w = smp[k];
-            cnt += (w.x == v.x && w.y == v.y && w.z == v.z) ? 1 : 0;
+        for (int k = 0; k < SPH_WAVE; ++k) { // (readlane: k is wave-uniform)
+            const float wx = __builtin_amdgcn_readlane(__float_as_int(v.x), k) == __float_as_int(v.x) ? 1.f : 0.f;
+            const bool same = wx != 0.f && __builtin_amdgcn_readlane(__float_as_int(v.y), k) == __float_as_int(v.y) &&
+                              __builtin_amdgcn_readlane(__float_as_int(v.z), k) == __float_as_int(v.z);
+            cnt += same ? 1 : 0;
         }
-        const int rank = cnt * 256 + (255 - t); // most matches, then the lowest sample
-        atomicMax(&best, rank);
-        __syncthreads();
-        if (best == rank) *X.vref = v;
+        // most matches, then the lowest sample: wave-wide max of cnt * 64 + (63 - lane)
+        int best = cnt * SPH_WAVE + (SPH_WAVE - 1 - lane);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if (best == cnt * SPH_WAVE + (SPH_WAVE - 1 - lane)) *X.vref = v;
     }
     bool valid = i < n;
     uint32_t k = valid ? skeys[i] : 0xFFFFFFFFu;
@@ -118,13 +118,13 @@ void sph_launch_gather(const float4 *pos_in, const float4 *vel_in,
                        const uint32_t *perm, const uint32_t *sorted_keys,
                        float4 *pos_out, float4 *vel_out, float4 *pv8, int2 *cellRange, int n,
                        hipStream_t s, const GatherExtras &X) {
-    if (n <= 0) { // nothing to gather: the riders still have to happen
+    if (n <= 0) { // nothing to gather: the riders still have to happen (no rows: no quiet bits to clear)
         if (X.cursor && X.cursorWords > 0)
             (void)hipMemsetAsync(X.cursor, 0, (size_t)X.cursorWords * sizeof(unsigned long long), s);
         if (X.bounds) sph_launch_lower_bounds(sorted_keys, 0, X.thr, X.nthr, X.bounds, s);
         return;
     }
-    const int threads = n > X.cursorWords ? n : X.cursorWords;
+    const int threads = std::max(n, std::max(X.cursorWords, X.quietWords));
     k_gather_cells<<<(threads + 255) / 256, 256, 0, s>>>(pos_in, vel_in, perm, sorted_keys,
                                                          pos_out, vel_out, pv8, cellRange, n, X);
 }

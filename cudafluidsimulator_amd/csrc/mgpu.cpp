@@ -1016,6 +1016,18 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
                 const int cD2 = (lo->nb_up.b[2] - lo->nb_up.b[1]) + (lo->mine.b[5] - lo->mine.b[4]);
                 if (cU != cU2 || cD != cD2) return fail(m, SPH_ESTATE, "exchange B plans disagree");
             }
+            if (m->opt.sweep == SPH_SWEEP_LIST) {
+                // the list sweeps read neighbours from the interleaved (pos4, vel4) records, into which the
+                // density sweep wrote rho: a boundary layer's records go straight into the neighbour's halo
+                // rows (twice the bytes of vel4 alone -- a few hundred KB -- and no patch launch afterwards)
+                F4 *rl = lo ? static_cast<F4 *>(sph_slab_records(lo->h)) : nullptr;
+                F4 *rh = hi ? static_cast<F4 *>(sph_slab_records(hi->h)) : nullptr;
+                msgs.push_back({r, r + 1, lo ? (const void *)(rl + 2 * (size_t)lo->s_hi) : nullptr,
+                                hi ? (void *)(rh + 2 * (size_t)(hi->i0 - cU)) : nullptr, (size_t)cU * 2 * sizeof(F4)});
+                msgs.push_back({r + 1, r, hi ? (const void *)(rh + 2 * (size_t)hi->i0) : nullptr,
+                                lo ? (void *)(rl + 2 * (size_t)lo->i1) : nullptr, (size_t)cD * 2 * sizeof(F4)});
+                continue;
+            }
             msgs.push_back({r, r + 1, lo ? (const void *)(lo->vel[lo->sbuf] + lo->s_hi) : nullptr,
                             hi ? (void *)(hi->vel[hi->sbuf] + hi->i0 - cU) : nullptr, (size_t)cU * sizeof(F4)});
             msgs.push_back({r + 1, r, hi ? (const void *)(hi->vel[hi->sbuf] + hi->i0) : nullptr,
@@ -1040,7 +1052,8 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
         if (m->shared_stream) {
             // loopback / self transport: exchange B was delivered in stream order, there is
             // nothing to overlap -- the whole slab in ONE launch (one tail instead of two)
-            SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb, nullptr));
+            if (m->opt.sweep != SPH_SWEEP_LIST) // (list: exchange B delivered whole records)
+                SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb, nullptr));
             SPHM(m, sl, sph_slab_force_ranges(sl.h, sl.sbuf, sl.i0, sl.i0, sl.i1, 0, 0, sl.n_comb, 1, nullptr));
         } else {
         // interior layers: every neighbour is an owned row -> no need to wait for exchange B
@@ -1050,7 +1063,7 @@ int step_phase4(sph_mgpu *m, SphTimes *times) {
         // tail (with a shared stream -- loopback -- they simply follow it)
         hipStream_t bs = sl.bnd ? sl.bnd : sl.s;
         if (sl.bnd) HIPM(m, hipStreamWaitEvent(sl.bnd, sl.evB, 0));
-        SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb, bs));
+        if (m->opt.sweep != SPH_SWEEP_LIST) SPHM(m, sl, sph_slab_patch_halo(sl.h, sl.sbuf, sl.i0, sl.i1, sl.n_comb, bs));
         SPHM(m, sl, sph_slab_force_ranges(sl.h, sl.sbuf, sl.i0, sl.i0, a, b, sl.i1, sl.n_comb, 1, bs));
         if (sl.bnd) {
             HIPM(m, hipEventRecord(sl.evBnd, sl.bnd));

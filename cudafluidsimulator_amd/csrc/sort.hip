@@ -59,64 +59,91 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // HASH: first pass of the grid build -- the key is computed from the particle's position
 // here (getGridCell + flattenGridCoord, simulator.cu:57-82) and stored for the scatter
 // passes, instead of a separate hash kernel writing keys and an iota of values.
+//
+// One workgroup per scatter tile (RS_THREADS * RS_ITEMS keys), but with a thread per FOUR keys
+// (1024 threads for a 4096-key tile) and all four loads in flight before the first is used:
+// round 2's form -- 256 threads walking 16 keys each, every load behind a branch -- was the
+// latency of 16 dependent HBM round trips with one load in flight per wave (93-106 us for 92 MB).
+// Counting needs no ranks, only run lengths: the input is the previous step's cell-sorted order, so
+// consecutive lanes mostly share a digit.  A lane whose left neighbour holds another digit is a
+// run HEAD (one DPP compare + ballot); it adds the distance to the next head to the tile
+// histogram: one LDS atomic per run instead of one per key, and no two lanes of a run on one
+// address (the "wave64 ballot boundary detection" of the north star).
+#define RS_HIST_ITEMS 4
 template <int BITS, bool HASH, int RS_ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(
+__global__ __launch_bounds__(RS_THREADS *RS_ITEMS / RS_HIST_ITEMS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
     int shift, int numBlocks, DevParams P, const float4 *__restrict__ pos4,
     uint32_t *__restrict__ keysOut, int2 *__restrict__ zeroTable, int zeroCount) {
-    constexpr int DIG = 1 << BITS, PER = DIG / RS_THREADS;
-    constexpr int RS_WAVE_TILE = SPH_WAVE * RS_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
+    constexpr int DIG = 1 << BITS;
+    constexpr int HT = RS_THREADS * RS_ITEMS / RS_HIST_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
+    constexpr int WAVE_KEYS = SPH_WAVE * RS_HIST_ITEMS;
     __shared__ uint32_t hist[DIG];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) hist[t + q * RS_THREADS] = 0;
+    for (int d = t; d < DIG; d += HT) hist[d] = 0;
+#ifndef RS_DBG_NOZERO
     if (HASH) // kernelResetGrid (simulator.cu:321-326): the cell table is cleared here, not by a launch of its own
-        for (int k = blockIdx.x * RS_THREADS + t; k < zeroCount; k += numBlocks * RS_THREADS)
+        for (int k = blockIdx.x * HT + t; k < zeroCount; k += numBlocks * HT)
             zeroTable[k] = make_int2(0, 0);
+#endif
     __syncthreads();
-    const long long base =
-        (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_TILE + lane;
+    // a wave owns WAVE_KEYS consecutive keys, RS_HIST_ITEMS rounds of 64
+    const long long base = (long long)blockIdx.x * RS_TILE + (long long)w * WAVE_KEYS + lane;
+    uint32_t key[RS_HIST_ITEMS];
+    if (HASH) {
+        float4 p[RS_HIST_ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        long long idx = base + r * SPH_WAVE;
-        bool valid = idx < n;
-        uint32_t key = 0u;
-        if (HASH) {
-            if (valid) {
-                const float4 p = pos4[idx];
-                // IEEE divide like the reference; cells clamped into the table (grid.hip)
-                const int cx = min(max((int)(p.x / P.h), 0), P.D - 1);
-                const int cy = min(max((int)(p.y / P.h), 0), P.D - 1);
-                const int cz = min(max((int)(p.z / P.h), 0), P.D - 1);
-                key = sph_cell_key(P, cx, cy, cz);
-                keysOut[idx] = key;
-            }
-        } else {
-            key = valid ? keys[idx] : 0u;
+        for (int r = 0; r < RS_HIST_ITEMS; ++r) {
+            const long long idx = base + r * SPH_WAVE;
+            p[r] = pos4[idx < n ? idx : (long long)n - 1]; // (n > 0; the clamped load is discarded)
         }
-        // Counting needs no ranks: one LDS atomic per key, except when the whole wave holds
-        // one digit (already-ordered streams: -i grid, the slab sorts), where the 64-way
-        // same-address add would serialise -- then one lane adds the wave's count.
-        const uint32_t d = (key >> shift) & (DIG - 1);
+#pragma unroll
+        for (int r = 0; r < RS_HIST_ITEMS; ++r) {
+            const long long idx = base + r * SPH_WAVE;
+            // IEEE divide like the reference; cells clamped into the table (grid.hip)
+#ifdef RS_DBG_NODIV
+            const int cx = min(max((int)(p[r].x * 10.f), 0), P.D - 1);
+            const int cy = min(max((int)(p[r].y * 10.f), 0), P.D - 1);
+            const int cz = min(max((int)(p[r].z * 10.f), 0), P.D - 1);
+#else
+            const int cx = min(max((int)(p[r].x / P.h), 0), P.D - 1);
+            const int cy = min(max((int)(p[r].y / P.h), 0), P.D - 1);
+            const int cz = min(max((int)(p[r].z / P.h), 0), P.D - 1);
+#endif
+            key[r] = sph_cell_key(P, cx, cy, cz);
+#ifndef RS_DBG_NOSTORE
+            if (idx < n) keysOut[idx] = key[r];
+#endif
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS_HIST_ITEMS; ++r) {
+            const long long idx = base + r * SPH_WAVE;
+            key[r] = keys[idx < n ? idx : (long long)n - 1];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RS_HIST_ITEMS; ++r) {
+        const long long idx = base + r * SPH_WAVE;
+        const bool valid = idx < n;
+        const uint32_t d = (key[r] >> shift) & (DIG - 1);
 #if RS_HIST_BALLOT
         unsigned long long mm = match_digit<BITS>(d, valid);
         if (valid && lanes_below(mm) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(mm));
 #else
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        const unsigned long long live = __ballot(valid);
-        if (__ballot(valid && d != d0) == 0ull && (live & 1ull)) {
-            if (lane == 0) atomicAdd(&hist[d0], (uint32_t)__popcll(live));
-        } else if (valid) {
-            atomicAdd(&hist[d], 1u);
+        const uint32_t dprev = __shfl_up(d, 1);
+        const unsigned long long live = __ballot(valid); // a prefix of the wave: lanes [0, count)
+        const unsigned long long heads = __ballot(valid && (lane == 0 || d != dprev));
+        if (valid && (lane == 0 || d != dprev)) {
+            // the next head above this lane, or the end of the valid lanes
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+            const int end = above ? __builtin_ctzll(above) : (int)__popcll(live);
+            atomicAdd(&hist[d], (uint32_t)(end - lane));
         }
 #endif
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int d = t + q * RS_THREADS;
-        blockHist[(size_t)d * numBlocks + blockIdx.x] = hist[d];
-    }
+    for (int d = t; d < DIG; d += HT) blockHist[(size_t)d * numBlocks + blockIdx.x] = hist[d];
 }
 
 // Block-wide inclusive scan of one value per thread (256 threads).
@@ -247,7 +274,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
                        int zeroCount = 0) {
     const int numBlocks = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
     if (pos4) { // first pass of the grid build: hash fused in, values = iota
-        k_radix_hist<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(nullptr, ws.blockHist, n, shift,
+        k_radix_hist<BITS, true, ITEMS><<<numBlocks, RS_THREADS * ITEMS / RS_HIST_ITEMS, 0, s>>>(nullptr, ws.blockHist, n, shift,
                                                                          numBlocks, *P, pos4, ws.keys[cur],
                                                                          zeroTable, zeroCount);
         k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
@@ -256,7 +283,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
             numBlocks);
         return;
     }
-    k_radix_hist<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
+    k_radix_hist<BITS, false, ITEMS><<<numBlocks, RS_THREADS * ITEMS / RS_HIST_ITEMS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
                                                                       numBlocks, DevParams{}, nullptr, nullptr, nullptr, 0);
     k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
     k_radix_scatter<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(

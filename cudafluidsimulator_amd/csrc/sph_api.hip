@@ -15,6 +15,7 @@
 #include "sph_c_api.h"
 #include "sph_device.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -94,6 +95,8 @@ struct sph_handle {
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
     float4 *quietVref = nullptr;     // ... and its reference velocity (device; written by the gather launch)
+    float4 *initPos4 = nullptr;      // setup()'s initial positions (+ids), kept on the device for the next setup()
+    int initZLayers = 0;
     bool useQuiet = true;            // SPH_ZERO_PAIR_FILTER=0 switches the filter off (A/B; same results)
     uint64_t hitsRecorded = 0;       // SPH_FLAG_COUNT_PAIRS: hits in the stream, before the filter
     unsigned long long *maskCursor = nullptr;
@@ -275,7 +278,9 @@ int alloc_device(sph_handle *h) {
         h->devPos[0] = h->devPos[1] = static_cast<float *>(dp);
         h->mappedPos = true;
     } else {
-        HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocDefault));
+        unsigned hostFlags = hipHostMallocDefault;
+        if (const char *e = getenv("SPH_HOSTPOS_NONCOHERENT")) if (atoi(e)) hostFlags = hipHostMallocNonCoherent; // study knob
+        HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hostFlags));
     }
     memset(h->hostPos, 0, posCap * 3 * sizeof(float));
     if (h->opt.sweep == SPH_SWEEP_LIST) {
@@ -411,6 +416,18 @@ int staged_upload(sph_handle *h, float4 *dev, size_t n, Fill fill) {
     return SPH_OK;
 }
 
+// host-side bookkeeping after the particle streams in buffer 0 were replaced
+void state_replaced(sph_handle *h) {
+    h->cur = 0;
+    drop_step_graphs(h);
+    h->ready = true;
+    h->gridValid = false;
+    h->phase = 0;
+    h->sorted = -1;
+    h->stepIndex = 0;
+    h->copyPending[0] = h->copyPending[1] = false;
+}
+
 int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
@@ -447,13 +464,7 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     }
     HIPCHK(h, hipDeviceSynchronize());
     h->zLayers = zmax >= zmin ? zmax - zmin + 1 : 0;
-    drop_step_graphs(h);
-    h->ready = true;
-    h->gridValid = false;
-    h->phase = 0;
-    h->sorted = -1;
-    h->stepIndex = 0;
-    h->copyPending[0] = h->copyPending[1] = false;
+    state_replaced(h);
     return SPH_OK;
 }
 
@@ -492,8 +503,9 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.maskCursor = h->maskCursor;
     A.maskCapacity = h->maskCapacity;
     A.pv8 = h->pv8;
-    // single domain only: a slab's owned range starts anywhere and its halo densities arrive later
-    A.quiet = (h->useQuiet && !h->external && h->n > 0) ? h->quiet : nullptr;
+    // (slabs: the wave origin is rounded down to a multiple of 64, the gather launch clears the array,
+    // so halo rows -- whose densities arrive after the density sweep -- stay "not quiet")
+    A.quiet = (h->useQuiet && h->quiet) ? h->quiet : nullptr;
     A.quietVref = h->quietVref;
     A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
@@ -509,7 +521,13 @@ GatherExtras gather_extras(sph_handle *h) {
         X.cursorWords = (int)(kCursorBytes / sizeof(unsigned long long));
         h->cursorClean = true;
     }
-    if (h->quiet && h->useQuiet && !h->external && h->n > 0) X.vref = h->quietVref;
+    if (h->quiet && h->useQuiet) {
+        X.vref = h->quietVref;
+        if (h->external) { // single domain: the density sweep rewrites every word each step
+            X.quietClear = h->quiet;
+            X.quietWords = (int)(2 * (((size_t)h->cap + 63) / 64) + 2);
+        }
+    }
     return X;
 }
 
@@ -586,6 +604,7 @@ int sph_bind_buffers(sph_handle *h, void *pos4_a, void *vel4_a, void *pos4_b, vo
 }
 
 void *sph_get_stream(sph_handle *h) { return h ? (void *)h->compute : nullptr; }
+void *sph_slab_records(sph_handle *h) { return (h && h->opt.sweep == SPH_SWEEP_LIST) ? (void *)h->pv8 : nullptr; }
 
 int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
                         const uint32_t *thresholds, int nthr, void *bounds_dev_out) {
@@ -714,7 +733,7 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     SweepArgs A = make_sweep_args(h);
     A.i_begin = i_begin;
     A.i_end = i_end;
-    A.i_origin = i_begin;
+    A.i_origin = i_begin & ~63; // hit-stream waves = whole words of the zero-pair filter's bit array
     A.n_all = n_all;
     A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
     A.force_out = nullptr;
@@ -738,7 +757,7 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     SweepArgs A = make_sweep_args(h);
     A.i_begin = i_begin;
     A.i_end = i_end;
-    A.i_origin = i_begin;
+    A.i_origin = i_begin & ~63;
     A.patchHalo = 1;
     A.n_all = n_all;
     A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
@@ -795,7 +814,7 @@ int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, 
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->compute;
     if (b0 > a0 || b1 > a1) {
         SweepArgs A = make_sweep_args(h);
-        A.i_origin = i_origin;
+        A.i_origin = i_origin & ~63; // (the same rounding as sph_slab_density)
         A.patchHalo = 0;
         A.n_all = n_all;
         A.force_out = nullptr;
@@ -982,6 +1001,7 @@ void sph_destroy(sph_handle *h) {
     if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->quiet) (void)hipFree(h->quiet);
     if (h->quietVref) (void)hipFree(h->quietVref);
+    if (h->initPos4) (void)hipFree(h->initPos4);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
     if (h->partTiles) (void)hipFree(h->partTiles);
     if (h->boundsHost) (void)hipHostFree(h->boundsHost);
@@ -998,10 +1018,41 @@ void sph_destroy(sph_handle *h) {
 int sph_setup(sph_handle *h) {
     if (!h) return SPH_EINVAL;
     const int n = h->n;
+    SPH_ON_DEVICE(h);
+    if (h->initPos4 && !h->external) {
+        // setup() again on the same handle (bench.py and the tests go back to the initial condition
+        // after their warm-up steps): the initial streams are restored from a device-resident copy
+        // instead of 12.6 M rand() calls, a validation pass and 134 MB over PCIe -- ~150 ms during
+        // which the GPU idles and after which its clocks need ~20 steps to come back
+        // (scripts/studies/clock_ramp.py: density sweep 0.63 -> 0.52 -> 0.47 ms over steps 1..40
+        // right after an upload, 0.48 flat behind a busy GPU).
+        HIPCHK(h, hipStreamSynchronize(h->compute));
+        HIPCHK(h, hipStreamSynchronize(h->copy));
+        HIPCHK(h, hipMemcpyAsync(h->pos4[0], h->initPos4, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, h->compute));
+        HIPCHK(h, hipMemsetAsync(h->vel4[0], 0, (size_t)n * sizeof(float4), h->compute));
+        HIPCHK(h, hipStreamSynchronize(h->compute));
+        h->zLayers = h->initZLayers;
+        state_replaced(h);
+        return SPH_OK;
+    }
     std::vector<float> pos((size_t)(n > 0 ? n : 1) * 3, 0.f);
     int rc = sph_initial_positions(&h->settings, pos.data());
     if (rc) return fail(h, rc, "sph_initial_positions failed");
-    return upload_common(h, pos.data(), nullptr, n);
+    rc = upload_common(h, pos.data(), nullptr, n);
+    if (rc || n <= 0 || h->external) return rc;
+    // keep the initial streams (best effort: without the copy the next setup() recomputes them)
+    if (hipMalloc(&h->initPos4, (size_t)n * sizeof(float4)) == hipSuccess) {
+        if (hipMemcpy(h->initPos4, h->pos4[0], (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice) == hipSuccess) {
+            h->initZLayers = h->zLayers;
+        } else {
+            (void)hipFree(h->initPos4);
+            h->initPos4 = nullptr;
+        }
+    } else {
+        h->initPos4 = nullptr;
+    }
+    (void)hipGetLastError();
+    return SPH_OK;
 }
 
 int sph_upload_state(sph_handle *h, const float *pos_xyz, const float *vel_xyz, int n) {
@@ -1109,9 +1160,14 @@ int sph_phase_readback(sph_handle *h) {
     HIPCHK(h, hipEventRecord(h->computeDone[slot], h->compute));
     HIPCHK(h, hipStreamWaitEvent(h->copy, h->computeDone[slot], 0));
     if (h->curEv) HIPCHK(h, hipEventRecord(h->curEv->c[0], h->copy));
-    if (h->n > 0)
-        HIPCHK(h, hipMemcpyAsync(h->hostPos, h->devPos[slot], (size_t)h->n * 3 * sizeof(float),
-                                 hipMemcpyDeviceToHost, h->copy));
+    if (h->n > 0) {
+        static const int chunks = getenv("SPH_COPY_CHUNKS") ? atoi(getenv("SPH_COPY_CHUNKS")) : 1; // study knob
+        const size_t total = (size_t)h->n * 3 * sizeof(float);
+        const size_t per = chunks > 1 ? ((total / chunks + 4095) & ~(size_t)4095) : total;
+        for (size_t off = 0; off < total; off += per)
+            HIPCHK(h, hipMemcpyAsync((char *)h->hostPos + off, (const char *)h->devPos[slot] + off,
+                                     std::min(per, total - off), hipMemcpyDeviceToHost, h->copy));
+    }
     if (h->curEv) {
         HIPCHK(h, hipEventRecord(h->curEv->c[1], h->copy));
         h->curEv->hasCopy = true;

@@ -93,7 +93,9 @@ struct GatherExtras {
     unsigned long long *cursor = nullptr; // hit-stream allocation cursors to clear ...
     int cursorWords = 0;                  // ... this many 8-byte words
     int *bounds = nullptr;                // slab path: bounds[t] = #keys < thr.v[t], bounds[nthr] = n
-    float4 *vref = nullptr;               // zero-pair filter: the most common velocity among 256 sampled rows goes here
+    float4 *vref = nullptr;               // zero-pair filter: the most common velocity among 64 sampled rows goes here
+    uint32_t *quietClear = nullptr;       // slab path: the filter's bit array is cleared here (halo rows stay "not quiet") ...
+    int quietWords = 0;                   // ... this many 32-bit words
     Thresholds thr{};
     int nthr = 0;
 };

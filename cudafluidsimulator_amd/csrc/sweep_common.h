@@ -139,9 +139,9 @@ __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float 
     float prs_j = fmaxf(0.f, SPH_GAS_CONSTANT * (rho_j - SPH_REST_DENSITY));
     if constexpr (SLIM) {
         // One basic block: the three Newton chains and the square root's corrections interleave, the
-        // gates become selects.  Adding +0 for a gated-out term is exact: F starts at +0 and an IEEE
-        // sum is -0 only if both operands are.  A coincident pair (dist = 0) makes NaNs that the
-        // selects discard.
+        // gates become selects.  Adding +-0 for a gated-out term is exact: F starts at +0 and an IEEE
+        // sum is -0 only if both operands are.  A coincident pair (dist = 0) makes NaNs / infinities
+        // in `scale` that the selects discard.
         const float dist = sw_sqrt(dist2);
         const bool tiny = dist < SPH_EPS_F;
         const bool inP = !(dist2 > P.h2) && !tiny, inV = !(dist > P.h) && !tiny;
@@ -150,20 +150,24 @@ __device__ __forceinline__ void force_pair(const DevParams &P, float pix, float 
         const float fPressure = 0.5f * sw_div_with(-SPH_MASS * (prs_i + prs_j), rho_j, rrho);
         const float scale = sw_div_with((-P.vcoef) * hd * hd, dist, sw_recip_refined(dist));
         const float fViscosity = sw_div_with(SPH_VISCOSITY * SPH_MASS * (P.vcoef * hd), rho_j, rrho);
-        float kx = dx * scale, ky = dy * scale, kz = dz * scale;
+        // the gates act on the two scalar factors (two selects instead of six): a gated-out term is
+        // then (finite) * 0 = +-0, which leaves the accumulators unchanged like the skipped addition
+        // (dx, dv and fPressure are finite: rho_j >= SPH_EPS_F)
+        const float scaleG = inP ? scale : 0.f, fViscG = inV ? fViscosity : 0.f;
+        float kx = dx * scaleG, ky = dy * scaleG, kz = dz * scaleG;
         kx *= fPressure;
         ky *= fPressure;
         kz *= fPressure;
         float dvx = vj.x - vix, dvy = vj.y - viy, dvz = vj.z - viz;
-        dvx *= fViscosity;
-        dvy *= fViscosity;
-        dvz *= fViscosity;
-        F.fx += inP ? kx : 0.f;
-        F.fy += inP ? ky : 0.f;
-        F.fz += inP ? kz : 0.f;
-        F.fx += inV ? dvx : 0.f;
-        F.fy += inV ? dvy : 0.f;
-        F.fz += inV ? dvz : 0.f;
+        dvx *= fViscG;
+        dvy *= fViscG;
+        dvz *= fViscG;
+        F.fx += kx;
+        F.fy += ky;
+        F.fz += kz;
+        F.fx += dvx;
+        F.fy += dvy;
+        F.fz += dvz;
     } else {
         float dist = sqrtf(dist2);
         bool tiny = dist < SPH_EPS_F;

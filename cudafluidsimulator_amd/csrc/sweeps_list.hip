@@ -60,6 +60,9 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_TRIVIAL_TEST
 #define SL_TRIVIAL_TEST 0
 #endif
+#ifndef SL_FETCH_UNIFORM
+#define SL_FETCH_UNIFORM 0
+#endif
 #ifndef SL_PV8
 #define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
@@ -103,7 +106,7 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 // reference's `-i random` run until the cloud reaches the floor, and the part of it still
 // falling afterwards.  The density sweep leaves one bit per sorted row: "no pressure, and the
 // velocity equals the reference velocity" (any reference is correct; the gather launch picks the
-// most common velocity among 256 sampled rows -- the last sorted row, the top of the highest
+// most common velocity among 64 sampled rows -- the last sorted row, the top of the highest
 // z-layer, was the first choice and went wrong at step 57 of the headline run, when splashes from
 // the floor opened a z-layer of their own); the force sweep of a quiet row clears the quiet
 // candidates out of its hit masks, 32 at a time.
@@ -151,8 +154,11 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
     unsigned long long accStage = 0, accTest = 0;
 #endif
     const int wv = xcd_tile(blockIdx.x, gridDim.x, A.tileChunk * (256 / SL_K1_THREADS), A.tileRotate) * (SL_K1_THREADS / SPH_WAVE) + w;
-    const int i = A.i_begin + wv * SPH_WAVE + lane;
-    const bool valid = i < A.i_end;
+    // waves are numbered from i_origin (<= i_begin, a multiple of 64 in slab mode so that a wave's
+    // 64 rows are one word of the zero-pair filter's bit array); rows below i_begin are not this launch's
+    const int i = A.i_origin + wv * SPH_WAVE + lane;
+    const bool valid = i >= A.i_begin && i < A.i_end;
+    const bool anyValid = __ballot(valid) != 0ull;
     float4 pi = valid ? A.pos4[i] : make_float4(0, 0, 0, 0);
     int3 c = sweep_cell(P, pi.x, pi.y, pi.z);
     int js[9], je[9];
@@ -179,7 +185,7 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
     const unsigned long long subCap = A.maskCapacity / SL_POOL_SHARDS;    // quads per sub-pool
     const bool ok = base + (unsigned long long)Q * SPH_WAVE <= subCap;    // wave-uniform
     base += (unsigned long long)shard * subCap;
-    if (lane == 0 && i < A.i_end) {
+    if (lane == 0 && anyValid) {
         A.maskOff[2 * (size_t)wv] = ok ? (uint32_t)base : SL_NONE;
         A.maskOff[2 * (size_t)wv + 1] = (uint32_t)Q;
     }
@@ -586,6 +592,23 @@ void k_force_list(DevParams P, SweepArgs A) {
             body(p, v);                                                        \
         }                                                                      \
     }
+#elif SL_WINDOW && SL_FETCH_UNIFORM
+        // experiment: every lane issues both loads of every fetch, so the gathers are straight-line
+        // code and the compiler can wait with exact vmcnt counts (two gathers really in flight);
+        // a lane whose hit is inside the LDS window loads the window's FIRST record instead (one
+        // wave-uniform address: one line for all such lanes, not a lane-request each).
+#define SL_FETCH(j, p, v)                                                      \
+    {                                                                          \
+        const size_t a_ = ((unsigned)((j)-w0) < (unsigned)wlen) ? (size_t)w0 : (size_t)(j); \
+        p = A.pv8[2 * a_];                                                     \
+        v = A.pv8[2 * a_ + 1];                                                 \
+    }
+#define SL_USE(j, p, v)                                                        \
+    if ((unsigned)((j)-w0) < (unsigned)wlen) {                                 \
+        p = win[2 * ((j)-w0)];                                                 \
+        v = win[2 * ((j)-w0) + 1];                                             \
+    }                                                                          \
+    body(p, v);
 #elif SL_WINDOW
         // fetch: issue the global gather only for lanes whose hit is outside the
         // window (fewer active lanes = fewer addresses for the TA); the LDS copy is
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(256) void k_count_hits(SweepArgs A) {
 void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMode, hipStream_t s) {
     int cnt = A.i_end - A.i_begin;
     if (cnt <= 0) return;
-    int blocks = (cnt + SL_K1_THREADS - 1) / SL_K1_THREADS;
+    int blocks = (A.i_end - A.i_origin + SL_K1_THREADS - 1) / SL_K1_THREADS; // waves are numbered from i_origin
     const bool same = P.cut2 == P.h2;
     if (mathMode == 1) {
         if (same) k_density_mask_lds<true, true><<<blocks, SL_K1_THREADS, 0, s>>>(P, A);

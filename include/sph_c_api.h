@@ -249,6 +249,11 @@ int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int cou
 int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
                         const uint32_t *thresholds, int nthr, void *bounds_dev_out);
 int sph_slab_patch_halo(sph_handle *h, int buf, int i_begin, int i_end, int n_all, void *hip_stream);
+/* SPH_SWEEP_LIST: the interleaved (pos4, vel4) records of the sorted rows (32 bytes per row, row r at
+ * byte 32 r; device pointer, NULL for the other sweeps).  The density sweep leaves rho in the record, so
+ * the driver can send a boundary layer's records straight into the neighbour's halo rows (exchange B)
+ * instead of sending vel4 rows and patching them in (sph_slab_patch_halo). */
+void *sph_slab_records(sph_handle *h);
 /* kernelMoveParticles (simulator.cu:329-367) for one slab: the impulse of sph_apply_click on the
  * z-layers [z_lo, z_hi) this slab owns, applied to the NEW state (buffer `buf`: the rows the last
  * sph_slab_force* launch wrote, still in that step's sorted order) through the cell table of that
