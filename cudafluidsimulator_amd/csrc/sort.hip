@@ -69,23 +69,36 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // run HEAD (one DPP compare + ballot); it adds the distance to the next head to the tile
 // histogram: one LDS atomic per run instead of one per key, and no two lanes of a run on one
 // address (the "wave64 ballot boundary detection" of the north star).
+// Positions whose cell lies outside the table: counted (and the first few recorded) in host-mapped
+// memory; the host prints the reference's diagnostic at its next synchronisation (sph_api.hip).
+__device__ __forceinline__ void oob_report(SphOobLog *log, float4 p, int ux, int uy, int uz) {
+    if (!log) return;
+    const uint32_t k = __hip_atomic_fetch_add(&log->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (k < SPH_OOB_RECORDS) {
+        log->rec[k].cell[0] = ux;
+        log->rec[k].cell[1] = uy;
+        log->rec[k].cell[2] = uz;
+        log->rec[k].pos[0] = p.x;
+        log->rec[k].pos[1] = p.y;
+        log->rec[k].pos[2] = p.z;
+    }
+}
+
 #define RS_HIST_ITEMS 4
 template <int BITS, bool HASH, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS *RS_ITEMS / RS_HIST_ITEMS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
     int shift, int numBlocks, DevParams P, const float4 *__restrict__ pos4,
-    uint32_t *__restrict__ keysOut, int2 *__restrict__ zeroTable, int zeroCount) {
+    uint32_t *__restrict__ keysOut, int2 *__restrict__ zeroTable, int zeroCount, SphOobLog *oob) {
     constexpr int DIG = 1 << BITS;
     constexpr int HT = RS_THREADS * RS_ITEMS / RS_HIST_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
     constexpr int WAVE_KEYS = SPH_WAVE * RS_HIST_ITEMS;
     __shared__ uint32_t hist[DIG];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int d = t; d < DIG; d += HT) hist[d] = 0;
-#ifndef RS_DBG_NOZERO
     if (HASH) // kernelResetGrid (simulator.cu:321-326): the cell table is cleared here, not by a launch of its own
         for (int k = blockIdx.x * HT + t; k < zeroCount; k += numBlocks * HT)
             zeroTable[k] = make_int2(0, 0);
-#endif
     __syncthreads();
     // a wave owns WAVE_KEYS consecutive keys, RS_HIST_ITEMS rounds of 64
     const long long base = (long long)blockIdx.x * RS_TILE + (long long)w * WAVE_KEYS + lane;
@@ -101,19 +114,17 @@ __global__ __launch_bounds__(RS_THREADS *RS_ITEMS / RS_HIST_ITEMS) void k_radix_
         for (int r = 0; r < RS_HIST_ITEMS; ++r) {
             const long long idx = base + r * SPH_WAVE;
             // IEEE divide like the reference; cells clamped into the table (grid.hip)
-#ifdef RS_DBG_NODIV
-            const int cx = min(max((int)(p[r].x * 10.f), 0), P.D - 1);
-            const int cy = min(max((int)(p[r].y * 10.f), 0), P.D - 1);
-            const int cz = min(max((int)(p[r].z * 10.f), 0), P.D - 1);
-#else
-            const int cx = min(max((int)(p[r].x / P.h), 0), P.D - 1);
-            const int cy = min(max((int)(p[r].y / P.h), 0), P.D - 1);
-            const int cz = min(max((int)(p[r].z / P.h), 0), P.D - 1);
-#endif
+            const int ux = (int)(p[r].x / P.h), uy = (int)(p[r].y / P.h), uz = (int)(p[r].z / P.h);
+            const int cx = min(max(ux, 0), P.D - 1);
+            const int cy = min(max(uy, 0), P.D - 1);
+            const int cz = min(max(uz, 0), P.D - 1);
+            // the reference's diagnostic (getGridCell, simulator.cu:60-73), once per step here instead of in
+            // every kernel that hashes a position; the cell is then clamped into the table where the
+            // reference would index out of bounds.  Never taken for states that came through
+            // setup()/upload_state() and the integrator's wall clamp (caller-owned slab buffers can).
+            if (idx < n && ((ux != cx) | (uy != cy) | (uz != cz))) oob_report(oob, p[r], ux, uy, uz);
             key[r] = sph_cell_key(P, cx, cy, cz);
-#ifndef RS_DBG_NOSTORE
             if (idx < n) keysOut[idx] = key[r];
-#endif
         }
     } else {
 #pragma unroll
@@ -276,7 +287,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
     if (pos4) { // first pass of the grid build: hash fused in, values = iota
         k_radix_hist<BITS, true, ITEMS><<<numBlocks, RS_THREADS * ITEMS / RS_HIST_ITEMS, 0, s>>>(nullptr, ws.blockHist, n, shift,
                                                                          numBlocks, *P, pos4, ws.keys[cur],
-                                                                         zeroTable, zeroCount);
+                                                                         zeroTable, zeroCount, ws.oob);
         k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
         k_radix_scatter<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
             ws.keys[cur], nullptr, ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist, ws.digitTotal, n, shift,
@@ -284,7 +295,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
         return;
     }
     k_radix_hist<BITS, false, ITEMS><<<numBlocks, RS_THREADS * ITEMS / RS_HIST_ITEMS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
-                                                                      numBlocks, DevParams{}, nullptr, nullptr, nullptr, 0);
+                                                                      numBlocks, DevParams{}, nullptr, nullptr, nullptr, 0, nullptr);
     k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
     k_radix_scatter<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
         ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist,

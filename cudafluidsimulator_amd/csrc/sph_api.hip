@@ -96,6 +96,8 @@ struct sph_handle {
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
     float4 *quietVref = nullptr;     // ... and its reference velocity (device; written by the gather launch)
     float4 *initPos4 = nullptr;      // setup()'s initial positions (+ids), kept on the device for the next setup()
+    SphOobLog *oobHost = nullptr;    // host-mapped: positions outside the grid met by the cell hash
+    uint32_t oobSeen = 0;            // how many of them were already reported
     int initZLayers = 0;
     bool useQuiet = true;            // SPH_ZERO_PAIR_FILTER=0 switches the filter off (A/B; same results)
     uint64_t hitsRecorded = 0;       // SPH_FLAG_COUNT_PAIRS: hits in the stream, before the filter
@@ -136,6 +138,27 @@ namespace {
         if (hipGetDevice(&d__) != hipSuccess || d__ != (h)->device)                    \
             HIPCHK(h, hipSetDevice((h)->device));                                     \
     } while (0)
+
+// The reference's out-of-grid diagnostic (getGridCell, simulator.cu:60-73), printed by the host after a
+// synchronisation instead of by device printf: the first sort pass logs such positions and clamps their
+// cell into the table (the reference indexes out of bounds there).
+void report_oob(sph_handle *h) {
+    if (!h || !h->oobHost) return;
+    const uint32_t cnt = h->oobHost->count;
+    if (cnt == h->oobSeen) return;
+    const int D = h->P.D;
+    const uint32_t shown = cnt < SPH_OOB_RECORDS ? cnt : SPH_OOB_RECORDS;
+    for (uint32_t k = h->oobSeen < shown ? h->oobSeen : shown; k < shown; ++k) {
+        const auto &r = h->oobHost->rec[k];
+        const char axis[3] = {'x', 'y', 'z'};
+        for (int a = 0; a < 3; ++a)
+            if (r.cell[a] < 0 || r.cell[a] >= D)
+                printf("OOB particle: %c = %d\n(%f, %f, %f)\n", axis[a], r.cell[a], r.pos[0], r.pos[1], r.pos[2]);
+    }
+    if (cnt > shown) printf("OOB particle: %u positions outside the grid so far (the first %u listed)\n", cnt, shown);
+    fflush(stdout);
+    h->oobSeen = cnt;
+}
 
 int fail(sph_handle *h, int code, const std::string &msg) {
     if (h) h->err = msg;
@@ -321,6 +344,13 @@ int alloc_device(sph_handle *h) {
         HIPCHK(h, hipMalloc(&h->quietVref, sizeof(float4)));
         HIPCHK(h, hipMemset(h->quietVref, 0, sizeof(float4)));
         if (const char *e = getenv("SPH_ZERO_PAIR_FILTER")) h->useQuiet = atoi(e) != 0;
+    }
+    HIPCHK(h, hipHostMalloc(&h->oobHost, sizeof(SphOobLog), hipHostMallocMapped));
+    memset(h->oobHost, 0, sizeof(SphOobLog));
+    {
+        void *dp = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, h->oobHost, 0));
+        h->ws.oob = static_cast<SphOobLog *>(dp);
     }
     HIPCHK(h, hipMalloc(&h->boundsDev, 16 * sizeof(int)));
     HIPCHK(h, hipMalloc(&h->partTiles, sph_partition_tiles((int)cap) * 9 * sizeof(int)));
@@ -1002,6 +1032,7 @@ void sph_destroy(sph_handle *h) {
     if (h->quiet) (void)hipFree(h->quiet);
     if (h->quietVref) (void)hipFree(h->quietVref);
     if (h->initPos4) (void)hipFree(h->initPos4);
+    if (h->oobHost) (void)hipHostFree(h->oobHost);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
     if (h->partTiles) (void)hipFree(h->partTiles);
     if (h->boundsHost) (void)hipHostFree(h->boundsHost);
@@ -1290,6 +1321,7 @@ int sph_step(sph_handle *h, SphTimes *times) {
     h->curEv = nullptr;
     if (times) {
         HIPCHK(h, hipStreamSynchronize(h->compute));
+        report_oob(h);
         float gridMs = 0.f, sphMs = 0.f;
         HIPCHK(h, hipEventElapsedTime(&gridMs, ev->e[0], ev->e[3]));
         HIPCHK(h, hipEventElapsedTime(&sphMs, ev->e[3], ev->e[5]));
@@ -1329,6 +1361,7 @@ const float *sph_positions_host(sph_handle *h) {
         h->err = "stream synchronize failed";
         return nullptr;
     }
+    report_oob(h);
     return h->hostPos;
 }
 
@@ -1433,6 +1466,7 @@ int sph_sync(sph_handle *h) {
     SPH_ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->compute));
     HIPCHK(h, hipStreamSynchronize(h->copy));
+    report_oob(h);
     return SPH_OK;
 }
 

@@ -63,6 +63,14 @@ __device__ __forceinline__ uint32_t sph_cell_key(const DevParams &P, int cx, int
 // 32 B per particle instead of the reference's 56-B AoS with a list pointer
 // (simulator.h:33-51); a neighbour test touches 16 B.
 
+// Out-of-grid positions met by the cell hash (the reference printf's "OOB particle" from the kernel,
+// simulator.cu:60-73): host-mapped, written by the first sort pass, printed by the host.
+#define SPH_OOB_RECORDS 8
+struct SphOobLog {
+    uint32_t count;
+    struct { int cell[3]; float pos[3]; } rec[SPH_OOB_RECORDS];
+};
+
 // ---- radix sort (sort.hip) ----
 struct SortWorkspace {
     uint32_t *keys[2];
@@ -71,6 +79,7 @@ struct SortWorkspace {
     uint32_t *digitTotal; // [digits]
     int capacity;         // elements
     int maxBlocks;
+    SphOobLog *oob;       // device view of the handle's out-of-grid log (may be null)
 };
 size_t sph_sort_workspace_blocks(int n);
 // Stable LSD sort of (keys[0], vals[0]) on `bits` key bits; returns the index

@@ -11,7 +11,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py --steps $K --warmup $W "$@" > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps $K --warmup $W --cpu-steps 0 --no-linked-leg --no-fast-leg --no-count-replay "$@" > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof exit $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps $K --warmup $W --cpu-steps 0 --no-linked-leg --no-fast-leg --no-count-replay --no-extra-legs "$@" > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof exit $?"
 # averages over the TIMED steps only (the last K dispatches of each kernel: settle and warm-up
 # steps come first) -- the figure bench.py's HIP-event average must agree with
 python3 - <<PY
@@ -33,7 +33,7 @@ find $OUT/prof -name "*kernel_trace.csv" -delete
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps $K --warmup $W --cpu-steps 0 --no-linked-leg --no-fast-leg --no-count-replay "$@" > $OUT/pmc$i.json 2> $OUT/pmc$i.err; echo "pmc pass $i exit $?"
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps $K --warmup $W --cpu-steps 0 --no-linked-leg --no-fast-leg --no-count-replay --no-extra-legs "$@" > $OUT/pmc$i.json 2> $OUT/pmc$i.err; echo "pmc pass $i exit $?"
 done
 cd $GRAFT_REPO_ROOT
 python3 scripts/pmc_summary.py $OUT $K > $OUT/pmc_summary.csv

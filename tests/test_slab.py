@@ -296,3 +296,32 @@ def test_hip_slab_config4_size_16M_particles_4_slabs():
     sim.close()
     assert_bit_equal(got[0], st["pos"], "16.7M particles, 4 slabs vs single domain: pos")
     assert_bit_equal(got[2], st["rho"], "16.7M particles, 4 slabs vs single domain: rho")
+
+
+@pytest.mark.gpu
+def test_out_of_grid_positions_are_reported_like_the_reference(capfd):
+    """getGridCell printf's "OOB particle: x = ..." and the position for a cell outside the table
+    (simulator.cu:60-73).  Positions that came through setup()/upload_state() and the integrator's
+    wall clamp never are; caller-owned slab buffers can hold anything: the first sort pass logs such
+    rows, clamps their cell into the table (no out-of-bounds index), and the host prints the
+    reference's two lines at its next synchronisation."""
+    n = 5000
+    settings = sph.default_settings(n, False)
+    be = S.HipSlabBackend(settings, n + 64)
+    rng = np.random.default_rng(1)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(1.0, 9.0, (n, 3))
+    pos[:, 3] = np.arange(n, dtype=np.uint32).view(np.float32)
+    pos[17, 0] = -0.15      # cell -1
+    pos[4000, 2] = 10.55    # cell 105 of 100
+    be.pos[0][:n] = torch.from_numpy(pos).to(be.device)
+    be.sort(0, 0, n, [])
+    torch.cuda.synchronize()
+    be._check(be._L.sph_sync(be._h), "sph_sync")
+    out = capfd.readouterr().out
+    assert "OOB particle: x = -1" in out and "OOB particle: z = 105" in out, out
+    assert "(-0.150000," in out and "10.550000)" in out
+    # clamped, not dropped: the sorted stream still holds every row
+    ids = be.pos[1][:n, 3].cpu().numpy().view(np.uint32)
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    be.close()
