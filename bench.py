@@ -413,7 +413,7 @@ def main():
                 for name, (ln, lk, lw) in {"config2_n262144_100steps": (262144, 100, 5),
                                            "config4_n16777216_single_gpu_10steps": (16777216, 10, 2)}.items():
                     ls = sph.default_settings(ln, True)
-                    lr = timed_run(sph, _lib, torch, ls, args, lk, lw, local_rank)
+                    lr = timed_run(sph, _lib, torch, ls, args, lk, lw, local_rank, settle=RUNTIME_SETTLE_STEPS)
                     legs[name] = {"workload": f"-n {ln} -i random -m time, first {lk} steps" if lk != 100 else
                                   f"-n {ln} -i random -m time (100 steps)",
                                   "value": ln * lk / lr["elapsed"], "unit": "particle-steps/s",
