@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_FETCH_UNIFORM
 #define SL_FETCH_UNIFORM 0
 #endif
+#ifndef SL_LDSDMA
+#define SL_LDSDMA 0
+#endif
 #ifndef SL_PV8
 #define SL_PV8 1 // gather one interleaved 32-B (pos4, vel4) record per hit: measured
                  // force sweep 1.80 -> ~1.55 ms (two loads, ONE cache line per lane)
@@ -486,6 +489,10 @@ void k_force_list(DevParams P, SweepArgs A) {
     // ds_read_b128 instead of a 64-address global gather.
     __shared__ float4 winAll[SL_K2_THREADS / SPH_WAVE][2 * SL_WINDOW];
     float4 *win = winAll[threadIdx.x >> 6];
+#if SL_LDSDMA
+    __shared__ float4 ringAll[SL_K2_THREADS / SPH_WAVE][2][2][SPH_WAVE];
+    float4(*ring)[2][SPH_WAVE] = ringAll[threadIdx.x >> 6];
+#endif
     const int tile0 = A.i_origin + tileIdx * blockDim.x + (threadIdx.x & ~63);
     const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
@@ -591,6 +598,27 @@ void k_force_list(DevParams P, SweepArgs A) {
             p = inw ? win[2 * ((j)-w0)] : A.pv8[2 * (size_t)(j)];              \
             body(p, v);                                                        \
         }                                                                      \
+    }
+#elif SL_WINDOW && SL_LDSDMA
+        // experiment: the gathers go through the LDS-DMA path -- per-lane
+        // `global_load_lds_dwordx4` into a two-slot ring in LDS (2 x 2 KB per wave), consumed by
+        // ds_read_b128 like the window's records: no VGPRs hold records in flight.
+#define SL_SLOT_p0 0
+#define SL_SLOT_p1 1
+#define SL_LDS_PTR(x) ((__attribute__((address_space(3))) void *)(x))
+#define SL_FETCH(j, p, v)                                                      \
+    if ((unsigned)((j)-w0) >= (unsigned)wlen) {                                \
+        __builtin_amdgcn_global_load_lds((const void *)(A.pv8 + 2 * (size_t)(j)), SL_LDS_PTR(&ring[SL_SLOT_##p][0][0]), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((const void *)(A.pv8 + 2 * (size_t)(j) + 1), SL_LDS_PTR(&ring[SL_SLOT_##p][1][0]), 16, 0, 0); \
+    }
+#define SL_USE(j, p, v)                                                        \
+    {                                                                          \
+        const bool inw_ = (unsigned)((j)-w0) < (unsigned)wlen;                 \
+        const float4 *a_ = inw_ ? &win[2 * ((j)-w0)] : &ring[SL_SLOT_##p][0][threadIdx.x & 63]; \
+        const float4 *b_ = inw_ ? a_ + 1 : a_ + SPH_WAVE;                      \
+        p = *a_;                                                               \
+        v = *b_;                                                               \
+        body(p, v);                                                            \
     }
 #elif SL_WINDOW && SL_FETCH_UNIFORM
         // experiment: every lane issues both loads of every fetch, so the gathers are straight-line
