@@ -349,44 +349,44 @@ void sph_launch_lower_bounds(const uint32_t *sorted_keys, int n, Thresholds thr,
     k_lower_bounds<<<1, 64, 0, s>>>(sorted_keys, n, thr, nthr, bounds_dev);
 }
 
-// kernelMoveParticles (simulator.cu:329-367), launched <<<1, numCellsPerDim>>>
-// like the reference (simulator.cu:483-486): thread t owns z-layer
-// (int)((float)t*h/h).  Velocities are edited in the sorted stream through the
-// cell table of the last grid build (the reference also uses the
-// pre-integration grid here).
-// zlo/zhi: only threads whose z-layer lies in [zlo, zhi) act (a slab applies the impulse to
-// the layers it owns; one domain: 0, D).
-__global__ void k_click(DevParams P, const int2 *__restrict__ cellRange,
-                        float4 *__restrict__ vel4, int mx, int my, int zlo, int zhi) {
-    float x = ((float)(mx - SPH_BOX_MIN_X) / (float)(SPH_BOX_MAX_X - SPH_BOX_MIN_X)) *
-              P.boxDim;
-    float y = ((float)(my - SPH_BOX_MIN_Y) / (float)(SPH_BOX_MAX_Y - SPH_BOX_MIN_Y)) *
-              P.boxDim;
-    float z = (float)threadIdx.x * P.h;
-    int cx = (int)(x / P.h);
-    int cy = (int)(y / P.h);
-    int cz = (int)(z / P.h);
-    cy = (int)((float)P.D - (float)cy);
-    if (cz < 0 || cz >= P.D || cz < zlo || cz >= zhi) return;
-    for (int dy = -2; dy < 3; dy++) {
-        int sy = cy + dy;
-        if (sy < 0 || sy >= P.D) continue;
-        for (int dx = -2; dx < 3; dx++) {
-            int sx = cx + dx;
-            if (sx < 0 || sx >= P.D) continue;
-            int2 r = cellRange[sph_cell_key(P, sx, sy, cz)];
-            for (int j = r.x; j < r.y; j++) {
-                float4 v = vel4[j];
-                if (dx != 0) v.x += (1.f / dx) * SPH_PUSH_STRENGTH;
-                if (dy != 0) v.y += (1.f / dy) * SPH_PUSH_STRENGTH;
-                if (dx == 0 && dy == 0) v.z -= SPH_PUSH_STRENGTH;
-                vel4[j] = v;
-            }
+// kernelMoveParticles (simulator.cu:329-367).  The reference launches <<<1, numCellsPerDim>>>: thread t
+// owns the z-layer (int)((float)t*h/h) and walks the 5 x 5 cells around the click through their
+// linked lists, one particle after the other; two t that round to the same layer race on the
+// velocities (the oracle applies them one after the other, sph_oracle.c).  Here: one 64-lane wave
+// per (cell of the 5 x 5 footprint, z-layer), the cell's particles in parallel through the cell
+// table of the last grid build (the pre-integration grid, like the reference); a wave first counts
+// how many of the reference's threads own its layer (0, 1 or 2) and applies the impulse that many
+// times in sequence -- the serial order's result, without the race.
+// zlo/zhi: only the layers [zlo, zhi) act (a slab applies the impulse to the layers it owns).
+__global__ __launch_bounds__(SPH_WAVE) void k_click(DevParams P, const int2 *__restrict__ cellRange,
+                                                    float4 *__restrict__ vel4, int mx, int my, int zlo, int zhi) {
+    const int cz = blockIdx.y, lane = threadIdx.x;
+    if (cz < zlo || cz >= zhi) return;
+    int owners = 0; // reference threads t with (int)((float)t * h / h) == cz
+    for (int t = lane; t < P.D; t += SPH_WAVE) owners += ((int)(((float)t * P.h) / P.h) == cz) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) owners += __shfl_xor(owners, off);
+    if (owners == 0) return;
+    const float x = ((float)(mx - SPH_BOX_MIN_X) / (float)(SPH_BOX_MAX_X - SPH_BOX_MIN_X)) * P.boxDim;
+    const float y = ((float)(my - SPH_BOX_MIN_Y) / (float)(SPH_BOX_MAX_Y - SPH_BOX_MIN_Y)) * P.boxDim;
+    const int cx = (int)(x / P.h);
+    const int cy = (int)((float)P.D - (float)(int)(y / P.h));
+    const int dy = (int)blockIdx.x / 5 - 2, dx = (int)blockIdx.x % 5 - 2;
+    const int sy = cy + dy, sx = cx + dx;
+    if (sy < 0 || sy >= P.D || sx < 0 || sx >= P.D) return;
+    const int2 r = cellRange[sph_cell_key(P, sx, sy, cz)];
+    for (int j = r.x + lane; j < r.y; j += SPH_WAVE) {
+        float4 v = vel4[j];
+        for (int k = 0; k < owners; ++k) {
+            if (dx != 0) v.x += (1.f / dx) * SPH_PUSH_STRENGTH;
+            if (dy != 0) v.y += (1.f / dy) * SPH_PUSH_STRENGTH;
+            if (dx == 0 && dy == 0) v.z -= SPH_PUSH_STRENGTH;
         }
+        vel4[j] = v;
     }
 }
 
 void sph_launch_click(const DevParams &P, const int2 *cellRange, float4 *vel4, int mx,
                       int my, hipStream_t s, int zlo, int zhi) {
-    k_click<<<1, P.D, 0, s>>>(P, cellRange, vel4, mx, my, zlo, zhi);
+    k_click<<<dim3(25, P.D), SPH_WAVE, 0, s>>>(P, cellRange, vel4, mx, my, zlo, zhi);
 }

@@ -133,6 +133,14 @@ struct sph_mgpu {
     bool overflow = false;
     int phase = 0;                 // phases of the current step already done (0..3)
     bool clickQueued = false;      // sph_mgpu_queue_click: applied by the step that completes next
+    // One process per GPU: a rank whose checks fail must not simply stop -- its neighbours would wait in
+    // their next grouped receive for ever (the status word only travels with the NEXT exchange A).
+    // A "poisoned" driver finishes the message rounds of the running step with the sizes the headers
+    // dictate (payload: whatever the buffers hold), posts ONE more exchange A whose header carries
+    // status = 1 -- the farewell -- and only then returns the error; a neighbour that reads status = 1
+    // does the same towards ITS other neighbours, one rank per step.  Compute is skipped.
+    bool poisoned = false;
+    int poisonCode = 0;
     int clickX = 0, clickY = 0;
     std::mutex errMu;              // fail() from worker threads
     Workers *workers = nullptr;    // SPH_MGPU_THREADS=1
@@ -148,6 +156,22 @@ int fail(sph_mgpu *m, int code, const std::string &msg) {
         g_create_error = msg;
     }
     return code;
+}
+
+// some rank of the run lives in another driver object (process): failures must be announced
+bool distributed(const sph_mgpu *m) { return (int)m->slabs.size() < m->opt.world; }
+
+// A check failed.  Every rank in this process: report at once.  Otherwise remember the first failure,
+// keep the step's message rounds going (see sph_mgpu::poisoned) and report at the end of the step.
+int poison(sph_mgpu *m, int code, const std::string &msg) {
+    if (!distributed(m)) return fail(m, code, msg);
+    if (!m->poisoned) {
+        m->poisoned = true;
+        m->poisonCode = code;
+        (void)fail(m, code, msg);
+        for (auto &sl : m->slabs) sl.status = 1;
+    }
+    return SPH_OK;
 }
 
 // Run fn(slab) for every local slab: in rank order on the calling thread, or on the slabs'
@@ -644,6 +668,7 @@ int upload_common(sph_mgpu *m, const float *pos, const float *vel, int n) {
         v4[i] = vel ? F4{vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.f} : F4{0.f, 0.f, 0.f, 0.f};
     }
     m->phase = 0; // a fresh state also clears whatever a failed step left half-done
+    m->poisoned = false;
     m->overflow = false;
     m->clickQueued = false;
     int rc = distribute(m, p4, v4);
@@ -872,20 +897,24 @@ int step_phase2(sph_mgpu *m) {
             const int *got = sl.pinned + 24;
             for (int k = 0; k < 4; ++k)
                 if (got[k] != sl.expect[k]) sl.status = 1;
-            if (sl.status)
-                return fail(m, SPH_ESTATE,
-                            "slab " + std::to_string(sl.rank) +
-                                ": a particle crossed into a neighbour slab beyond its far boundary layer "
-                                "(or out of it) in one step: z-velocity too high for this decomposition");
+            if (sl.status) {
+                int rc = poison(m, SPH_ESTATE,
+                                "slab " + std::to_string(sl.rank) +
+                                    ": a particle crossed into a neighbour slab beyond its far boundary layer "
+                                    "(or out of it) in one step: z-velocity too high for this decomposition");
+                if (rc) return rc;
+            }
         }
         if ((sl.has_dn && sl.nb_dn.status) || (sl.has_up && sl.nb_up.status)) {
             sl.status = 1;
-            return fail(m, SPH_ESTATE, "slab " + std::to_string(sl.rank) + ": a neighbour slab reported a failure");
+            int rc = poison(m, SPH_ESTATE, "slab " + std::to_string(sl.rank) + ": a neighbour slab reported a failure");
+            if (rc) return rc;
         }
-        if (!sl.has_dn && sl.mine.b[1] != 0) return fail(m, SPH_ESTATE, "particles below the lowest slab");
-        if (!sl.has_up && sl.mine.b[4] != sl.mine.n) return fail(m, SPH_ESTATE, "particles above the highest slab");
-        if (sl.has_dn && (down_layout(sl.mine, F).extra || up_layout(sl.nb_dn, F).extra)) overflow = true;
-        if (sl.has_up && (up_layout(sl.mine, F).extra || down_layout(sl.nb_up, F).extra)) overflow = true;
+        if (!sl.has_dn && sl.mine.b[1] != 0) { int rc = poison(m, SPH_ESTATE, "particles below the lowest slab"); if (rc) return rc; }
+        if (!sl.has_up && sl.mine.b[4] != sl.mine.n) { int rc = poison(m, SPH_ESTATE, "particles above the highest slab"); if (rc) return rc; }
+        // (a neighbour that has said farewell takes part in no further round)
+        if (sl.has_dn && !sl.nb_dn.status && (down_layout(sl.mine, F).extra || up_layout(sl.nb_dn, F).extra)) overflow = true;
+        if (sl.has_up && !sl.nb_up.status && (up_layout(sl.mine, F).extra || down_layout(sl.nb_up, F).extra)) overflow = true;
     }
     // ---- 3b. (rare) a face outgrew its fixed-size message: exact-size second round
     if (overflow) {
@@ -900,6 +929,7 @@ int step_phase2(sph_mgpu *m) {
         for (int r = 0; r + 1 < m->opt.world; ++r) {
             Slab *lo = local(m, r), *hi = local(m, r + 1);
             if (!lo && !hi) continue;
+            if ((lo && lo->nb_up.status) || (hi && hi->nb_dn.status)) continue; // that neighbour is gone
             // UP excess of r: rows [b3, b3+extra) of its partitioned array -> hi.ex[0]
             const int exU = lo ? up_layout(lo->mine, F).extra : up_layout(hi->nb_dn, F).extra;
             if (exU) {
@@ -941,13 +971,19 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
         int o[8] = {0};
         for (int k = 0; k < 7; ++k) o[k + 1] = o[k] + counts[k];
         sl.n_comb = o[7];
-        if (sl.n_comb > m->cap) return fail(m, SPH_ESTATE, "slab capacity exceeded by halo + migrants");
         sl.i0 = bnd_from_dn + m0;
         sl.i1 = sl.n_comb - (bnd_from_up + (n - m3));
         sl.e_lo = sl.i0 + near_from_dn + (m1 - m0);
         sl.s_hi = sl.i1 - (near_from_up + (m3 - m2));
-        if (sl.i0 > sl.e_lo || sl.e_lo > sl.s_hi || sl.s_hi > sl.i1)
-            return fail(m, SPH_ESTATE, "slab " + std::to_string(sl.rank) + ": inconsistent exchange headers");
+        if (sl.n_comb > m->cap) {
+            int rc = poison(m, SPH_ESTATE, "slab capacity exceeded by halo + migrants");
+            if (rc) return rc;
+        }
+        if (sl.i0 > sl.e_lo || sl.e_lo > sl.s_hi || sl.s_hi > sl.i1) {
+            int rc = poison(m, SPH_ESTATE, "slab " + std::to_string(sl.rank) + ": inconsistent exchange headers");
+            if (rc) return rc;
+        }
+        if (m->poisoned) return SPH_OK; // the state is lost; only the step's remaining messages matter
         const int s = sl.sbuf, t = s ^ 1;
         std::vector<Piece> pieces;
         std::vector<int> dst;
@@ -1016,6 +1052,18 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
                 const int cD2 = (lo->nb_up.b[2] - lo->nb_up.b[1]) + (lo->mine.b[5] - lo->mine.b[4]);
                 if (cU != cU2 || cD != cD2) return fail(m, SPH_ESTATE, "exchange B plans disagree");
             }
+            if ((lo && lo->nb_up.status) || (hi && hi->nb_dn.status)) continue; // that neighbour has said farewell
+            if (m->poisoned) {
+                // sizes as the headers dictate (the healthy neighbour posts the matching calls), payload and
+                // destination anywhere inside the buffers: nothing will read them
+                const size_t rowB = (m->opt.sweep == SPH_SWEEP_LIST ? 2 : 1) * sizeof(F4);
+                if (cU < 0 || cD < 0 || cU > m->cap || cD > m->cap) return fail(m, SPH_ESTATE, "failed step: exchange sizes out of range");
+                F4 *bl = lo ? (m->opt.sweep == SPH_SWEEP_LIST ? static_cast<F4 *>(sph_slab_records(lo->h)) : lo->vel[0]) : nullptr;
+                F4 *bh = hi ? (m->opt.sweep == SPH_SWEEP_LIST ? static_cast<F4 *>(sph_slab_records(hi->h)) : hi->vel[0]) : nullptr;
+                msgs.push_back({r, r + 1, bl, bh, (size_t)cU * rowB});
+                msgs.push_back({r + 1, r, bh, bl, (size_t)cD * rowB});
+                continue;
+            }
             if (m->opt.sweep == SPH_SWEEP_LIST) {
                 // the list sweeps read neighbours from the interleaved (pos4, vel4) records, into which the
                 // density sweep wrote rho: a boundary layer's records go straight into the neighbour's halo
@@ -1034,7 +1082,11 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
                             lo ? (void *)(lo->vel[lo->sbuf] + lo->i1) : nullptr, (size_t)cD * sizeof(F4)});
         }
         for (auto &sl : m->slabs)
-            if (sl.comm) { HIPM(m, hipSetDevice(sl.device)); HIPM(m, hipStreamWaitEvent(sl.comm, sl.evDensity, 0)); }
+            if (sl.comm) {
+                HIPM(m, hipSetDevice(sl.device));
+                if (m->poisoned) HIPM(m, hipEventRecord(sl.evDensity, sl.s)); // (no density sweep recorded it)
+                HIPM(m, hipStreamWaitEvent(sl.comm, sl.evDensity, 0));
+            }
         int rc = deliver(m, msgs, true);
         if (rc) return rc;
         for (auto &sl : m->slabs)
@@ -1043,9 +1095,47 @@ int step_phase3(sph_mgpu *m, SphTimes *times) {
     return SPH_OK;
 }
 
+// The farewell of a poisoned driver: one more exchange A (header with status = 1 + the fixed-size windows)
+// with every neighbour in another process that has not said farewell itself -- exactly the calls that
+// neighbour posts in phase 1 of its next step -- then the error of the failed check.
+int farewell(sph_mgpu *m) {
+    const int F = m->F;
+    const size_t W = (size_t)F * sizeof(F4);
+    std::vector<Msg> msgs;
+    for (auto &sl : m->slabs) {
+        HIPM(m, hipSetDevice(sl.device));
+        if (sl.bnd) HIPM(m, hipStreamSynchronize(sl.bnd));
+        if (sl.comm) HIPM(m, hipStreamSynchronize(sl.comm)); // exchange B of this step is through
+        Hdr bye{};
+        bye.status = 1;
+        memcpy(sl.pinned, &bye, sizeof(Hdr));
+        HIPM(m, hipMemcpyAsync(sl.hdr_tx, sl.pinned, sizeof(Hdr), hipMemcpyHostToDevice, sl.s));
+    }
+    for (int r = 0; r + 1 < m->opt.world; ++r) {
+        Slab *lo = local(m, r), *hi = local(m, r + 1);
+        if ((lo != nullptr) == (hi != nullptr)) continue; // both here (stopping together) or both elsewhere
+        if ((lo && lo->nb_up.status) || (hi && hi->nb_dn.status)) continue; // gone already
+        msgs.push_back({r, r + 1, lo ? (const void *)lo->hdr_tx : nullptr, hi ? (void *)&hi->hdr_rx[0] : nullptr, sizeof(Hdr)});
+        msgs.push_back({r, r + 1, lo ? (const void *)lo->pos[0] : nullptr, hi ? (void *)hi->rx_pos[0] : nullptr, W});
+        msgs.push_back({r, r + 1, lo ? (const void *)lo->vel[0] : nullptr, hi ? (void *)hi->rx_vel[0] : nullptr, W});
+        msgs.push_back({r + 1, r, hi ? (const void *)hi->hdr_tx : nullptr, lo ? (void *)&lo->hdr_rx[1] : nullptr, sizeof(Hdr)});
+        msgs.push_back({r + 1, r, hi ? (const void *)hi->pos[0] : nullptr, lo ? (void *)lo->rx_pos[1] : nullptr, W});
+        msgs.push_back({r + 1, r, hi ? (const void *)hi->vel[0] : nullptr, lo ? (void *)lo->rx_vel[1] : nullptr, W});
+    }
+    int rc = deliver(m, msgs, false);
+    if (rc) return rc;
+    if (m->opt.transport != SPH_TRANSPORT_MAILBOX)
+        for (auto &sl : m->slabs) {
+            HIPM(m, hipSetDevice(sl.device));
+            HIPM(m, hipStreamSynchronize(sl.s));
+        }
+    return m->poisonCode; // (m->err still holds the message of the check that failed)
+}
+
 int step_phase4(sph_mgpu *m, SphTimes *times) {
     int rc0 = resolve_mail(m);
     if (rc0) return rc0;
+    if (m->poisoned) return farewell(m);
     int rcl = for_each_slab(m, [&](Slab &sl) -> int {
         HIPM(m, hipSetDevice(sl.device));
         const int a = sl.has_dn ? sl.e_lo : sl.i0, b = sl.has_up ? sl.s_hi : sl.i1;
@@ -1125,10 +1215,14 @@ extern "C" {
 int sph_mgpu_step_phase(sph_mgpu *m, int phase, SphTimes *times) {
     if (!m) return SPH_EINVAL;
     if (!m->ready) return fail(m, SPH_ESTATE, "setup()/upload_state() must come first");
+    if (m->poisoned && m->phase == 0) return m->poisonCode; // (err holds the message; upload_state()/setup() starts over)
     if (phase < 1 || phase > 4 || phase != m->phase + 1) return fail(m, SPH_ESTATE, "step phases run 1, 2, 3, 4");
     int rc = phase == 1 ? step_phase1(m, times) : phase == 2 ? step_phase2(m)
              : phase == 3 ? step_phase3(m, times) : step_phase4(m, times);
-    if (rc) return rc;
+    if (rc) {
+        if (m->poisoned && phase == 4) m->phase = 0; // farewell sent: every later step reports the same failure
+        return rc;
+    }
     m->phase = phase == 4 ? 0 : phase;
     return SPH_OK;
 }

@@ -250,6 +250,62 @@ def test_click_impulse_in_multi_gpu_mode(world, transport, recut):
 
 
 @pytest.mark.gpu
+def test_one_rank_failing_stops_its_neighbours_with_an_error_not_a_hang():
+    """One process per GPU (here: one driver object per rank, mailbox transport, stepped phase by
+    phase): a particle that crosses a whole slab in one step makes ONE rank's check fail.  That
+    rank finishes the step's message rounds, says farewell (an exchange A whose header carries
+    status = 1) and returns the error; its neighbours read the status in their next step, do the
+    same and return an error too -- nobody is left waiting for a message (the mailbox would report
+    "the sending rank has not run this phase yet", RCCL would hang).  A fresh state then runs."""
+    n, world = 60000, 3
+    pos, vel = moving_state(n, 21, vz=3.0)
+    k = int(np.argmin(pos[:, 2]))
+    vel[k] = (0.0, 0.0, 650.0)          # 65 cells per step: from slab 0 across slab 1 into slab 2
+    settings = sph.default_settings(n, False)
+    ranks = [M.MultiGpuSimulator(settings, world=world, rank=r, devices=[0], transport="mailbox") for r in range(world)]
+    for mg in ranks:
+        mg.upload_state(pos, vel)
+    died = {}
+    for step in range(1, 8):
+        for phase in (1, 2, 3, 4):
+            for r, mg in enumerate(ranks):
+                if r in died:
+                    continue
+                try:
+                    mg.step_phase(phase)
+                except sph.SphError as e:
+                    died[r] = (step, phase, str(e))
+        if len(died) == world:
+            break
+    assert len(died) == world, died
+    assert all(ph == 4 for _, ph, _ in died.values()), died          # errors surface at the END of a step
+    assert not any("mailbox" in msg for _, _, msg in died.values()), died
+    first = min(died.values())[0]
+    origin = [r for r, d in died.items() if d[0] == first]
+    assert origin == [1] and "crossed" in died[1][2], died
+    assert died[0][0] == died[2][0] == first + 1 and "neighbour slab reported a failure" in died[0][2], died
+    with pytest.raises(sph.SphError):                                # ... and keep being reported
+        ranks[1].step_phase(1)
+    # a fresh state: the same objects run again, bit-equal to the single domain
+    pos2, vel2 = moving_state(n, 22, vz=8.0)
+    want, _ = single_domain(settings, pos2, vel2, 3)
+    for mg in ranks:
+        mg.upload_state(pos2, vel2)
+    for _ in range(3):
+        for phase in (1, 2, 3, 4):
+            for mg in ranks:
+                mg.step_phase(phase)
+    got = np.full((n, 3), np.nan, np.float32)
+    for mg in ranks:
+        d = mg.download_state()
+        m_ = ~np.isnan(d["pos"][:, 0])
+        got[m_] = d["pos"][m_]
+    assert_bit_equal(got, want["pos"], "after the failed run: pos")
+    for mg in ranks:
+        mg.close()
+
+
+@pytest.mark.gpu
 def test_sinking_fluid_recut_moves_the_cuts():
     """Mass that drifts along z makes the static cuts lopsided; the re-cut follows it."""
     n, world = 60000, 4
