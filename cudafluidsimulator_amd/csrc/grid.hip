@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     // cursors are cleared for the density sweep that follows ...
     if (i < X.cursorWords) X.cursor[i] = 0ull;
     if (i < X.quietWords) X.quietClear[i] = 0u;
+    if (X.quietAll && i == 0) *X.quietAll = 1u;
     // ... the force sweep's zero-pair filter gets its reference velocity: the most common one among
     // 64 rows sampled evenly from the (unsorted) input -- a body of fluid in free fall shares one
     // velocity bit for bit; any choice is correct, a popular one drops the most pairs ...

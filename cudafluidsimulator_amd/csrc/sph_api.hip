@@ -60,7 +60,20 @@ struct sph_handle {
     int sorted = -1; // buffers holding the sorted streams of the last grid build
     SortWorkspace ws{};
     int sortedKeyBuf = 0;
-    int2 *cellRange = nullptr;
+    int2 *cellRange = nullptr;       // the cell table of the LAST grid build (= cellTable[cellCur])
+    int2 *cellTable[2] = {nullptr, nullptr}; // two tables: a grid built ahead (below) must not clobber the last step's
+    int cellCur = 0;
+    // Step pipelining (timed steps): simulateAndTime() has to wait for its step, and between that wait and the
+    // first launch of the next call the GPU idled ~0.12 ms per step (host: two event queries, the return to the
+    // caller -- Python in bench.py --, the next call's first launches).  A timed step therefore queues the NEXT
+    // step's grid build (which only needs the state this step leaves behind) BEFORE it waits, and waits for its
+    // own force event instead of the whole stream; the next step finds its grid built.  Anything that changes
+    // or replaces the state in between (click, upload, load) simply drops the grid built ahead.
+    bool gridAhead = false;
+    int2 *clickTable = nullptr;      // cell table of the last COMPLETED step (what sph_apply_click walks)
+    bool clickValid = false;
+    bool aheadEnabled = true;        // default: below 1.5 M particles; SPH_PIPELINE=0/1 forces it (same results)
+    StepEvents *aheadEv = nullptr;
     float *devPos[2] = {nullptr, nullptr};
     float *hostPos = nullptr; // pinned, n*3
     // Pinned staging for state uploads (two halves, ping-pong).  A hipMemcpy from pageable
@@ -98,6 +111,12 @@ struct sph_handle {
     float4 *initPos4 = nullptr;      // setup()'s initial positions (+ids), kept on the device for the next setup()
     SphOobLog *oobHost = nullptr;    // host-mapped: positions outside the grid met by the cell hash
     uint32_t oobSeen = 0;            // how many of them were already reported
+    // SPH_STEP_TRACE=1 (diagnostic): where the HOST spends a timed step, printed by sph_destroy
+    bool trace = false;
+    double trEnqueue = 0, trSync = 0, trPost = 0, trBetween = 0, trPh[5] = {0, 0, 0, 0, 0};
+    long long trSteps = 0;
+    std::chrono::steady_clock::time_point trLastReturn{};
+    hipEvent_t trBase = nullptr;     // first traced step's start: GPU-side timeline of every later step
     int initZLayers = 0;
     bool useQuiet = true;            // SPH_ZERO_PAIR_FILTER=0 switches the filter off (A/B; same results)
     uint64_t hitsRecorded = 0;       // SPH_FLAG_COUNT_PAIRS: hits in the stream, before the filter
@@ -291,8 +310,15 @@ int alloc_device(sph_handle *h) {
                         (size_t)1024 * (size_t)(h->ws.maxBlocks > 0 ? h->ws.maxBlocks : 1) *
                             sizeof(uint32_t)));
     HIPCHK(h, hipMalloc(&h->ws.digitTotal, 1024 * sizeof(uint32_t)));
-    HIPCHK(h, hipMalloc(&h->cellRange, (size_t)h->P.numCells * sizeof(int2)));
-    HIPCHK(h, hipMemset(h->cellRange, 0, (size_t)h->P.numCells * sizeof(int2)));
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(h, hipMalloc(&h->cellTable[b], (size_t)h->P.numCells * sizeof(int2)));
+        HIPCHK(h, hipMemset(h->cellTable[b], 0, (size_t)h->P.numCells * sizeof(int2)));
+    }
+    h->cellRange = h->cellTable[0];
+    // measured (profiles/r03_experiments.md): n = 262,144: 0.170 -> 0.149 ms per step; n = 4,194,304: nothing
+    // (the early steps are bound by the read-back, and beside more GPU work its blit kernel slows down)
+    h->aheadEnabled = h->n < (3 << 19);
+    if (const char *e = getenv("SPH_PIPELINE")) h->aheadEnabled = atoi(e) != 0;
     if (h->opt.flags & SPH_FLAG_MAPPED_POSITIONS) {
         // zero-copy: the force sweep's id-ordered scatter goes over PCIe into this buffer
         HIPCHK(h, hipHostMalloc(&h->hostPos, posCap * 3 * sizeof(float), hipHostMallocMapped));
@@ -341,8 +367,8 @@ int alloc_device(sph_handle *h) {
         const size_t quietWords = 2 * ((cap + 63) / 64) + 2;
         HIPCHK(h, hipMalloc(&h->quiet, quietWords * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->quiet, 0, quietWords * sizeof(uint32_t)));
-        HIPCHK(h, hipMalloc(&h->quietVref, sizeof(float4)));
-        HIPCHK(h, hipMemset(h->quietVref, 0, sizeof(float4)));
+        HIPCHK(h, hipMalloc(&h->quietVref, 2 * sizeof(float4))); // [0] the reference velocity, [1].x the all-quiet word
+        HIPCHK(h, hipMemset(h->quietVref, 0, 2 * sizeof(float4)));
         if (const char *e = getenv("SPH_ZERO_PAIR_FILTER")) h->useQuiet = atoi(e) != 0;
     }
     HIPCHK(h, hipHostMalloc(&h->oobHost, sizeof(SphOobLog), hipHostMallocMapped));
@@ -412,6 +438,14 @@ int resolve_events(sph_handle *h, StepEvents &se) {
     h->kt.steps += 1;
     se.counted = true;
     se.used = false;
+    if (h->trace && h->trBase && se.hasCopy) { // GPU-side timeline (ms since the first traced step began)
+        float t0 = 0, t3 = 0, t5 = 0, c0 = 0, c1 = 0;
+        if (hipEventElapsedTime(&t0, h->trBase, se.e[0]) == hipSuccess && hipEventElapsedTime(&t3, h->trBase, se.e[3]) == hipSuccess &&
+            hipEventElapsedTime(&t5, h->trBase, se.e[5]) == hipSuccess && hipEventElapsedTime(&c0, h->trBase, se.c[0]) == hipSuccess &&
+            hipEventElapsedTime(&c1, h->trBase, se.c[1]) == hipSuccess)
+            fprintf(stderr, "sph timeline: grid %.3f..%.3f sweeps ..%.3f | copy %.3f..%.3f\n", t0, t3, t5, c0, c1);
+        (void)hipGetLastError();
+    }
     return SPH_OK;
 }
 
@@ -447,7 +481,19 @@ int staged_upload(sph_handle *h, float4 *dev, size_t n, Fill fill) {
 }
 
 // host-side bookkeeping after the particle streams in buffer 0 were replaced
+// forget a grid that was built ahead for a state that is no longer the current one
+void drop_grid_ahead(sph_handle *h) {
+    if (!h->gridAhead) return;
+    h->gridAhead = false;
+    if (h->aheadEv) h->aheadEv->used = false; // (its density / force events were never recorded)
+    h->aheadEv = nullptr;
+    h->gridValid = false;
+    h->phase = 0;
+}
+
 void state_replaced(sph_handle *h) {
+    drop_grid_ahead(h);
+    h->clickValid = false;
     h->cur = 0;
     drop_step_graphs(h);
     h->ready = true;
@@ -537,6 +583,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     // so halo rows -- whose densities arrive after the density sweep -- stay "not quiet")
     A.quiet = (h->useQuiet && h->quiet) ? h->quiet : nullptr;
     A.quietVref = h->quietVref;
+    A.quietAll = (A.quiet && !h->external) ? reinterpret_cast<uint32_t *>(h->quietVref + 1) : nullptr;
     A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
     A.listNext = reinterpret_cast<const int *>(h->ws.vals[0]);
@@ -553,6 +600,7 @@ GatherExtras gather_extras(sph_handle *h) {
     }
     if (h->quiet && h->useQuiet) {
         X.vref = h->quietVref;
+        if (!h->external) X.quietAll = reinterpret_cast<uint32_t *>(h->quietVref + 1);
         if (h->external) { // single domain: the density sweep rewrites every word each step
             X.quietClear = h->quiet;
             X.quietWords = (int)(2 * (((size_t)h->cap + 63) / 64) + 2);
@@ -966,6 +1014,7 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
     else h->cap = h->opt.capacity > h->n ? h->opt.capacity : h->n;
     if (const char *e = getenv("SPH_TILE_CHUNK")) h->tileChunkEnv = atoi(e); // tuning studies
     if (const char *e = getenv("SPH_XCD_ROTATE")) h->tileRotate = atoi(e);
+    if (const char *e = getenv("SPH_STEP_TRACE")) h->trace = atoi(e) != 0;
     fill_params(h);
     int rc = SPH_OK;
     do {
@@ -992,6 +1041,12 @@ int sph_create(const SphSettings *settings, const SphOptions *options, sph_handl
 
 void sph_destroy(sph_handle *h) {
     if (!h) return;
+    if (h->trace && h->trSteps > 0)
+        fprintf(stderr, "sph step trace (host, us per timed step over %lld steps): enqueue %.1f | wait for the compute stream %.1f | "
+                        "after the wait %.1f | caller between two steps %.1f\n", h->trSteps, h->trEnqueue / h->trSteps * 1e6,
+                h->trSync / h->trSteps * 1e6, h->trPost / h->trSteps * 1e6, h->trBetween / (h->trSteps > 1 ? h->trSteps - 1 : 1) * 1e6),
+        fprintf(stderr, "  enqueue split: events %.1f | grid %.1f | density %.1f | force %.1f | read-back %.1f\n", h->trPh[0] / h->trSteps * 1e6,
+                h->trPh[1] / h->trSteps * 1e6, h->trPh[2] / h->trSteps * 1e6, h->trPh[3] / h->trSteps * 1e6, h->trPh[4] / h->trSteps * 1e6);
     if (h->compute) (void)hipStreamSynchronize(h->compute);
     if (h->copy) (void)hipStreamSynchronize(h->copy);
     for (int b = 0; b < 2; ++b) {
@@ -1005,7 +1060,7 @@ void sph_destroy(sph_handle *h) {
     }
     if (h->ws.blockHist) (void)hipFree(h->ws.blockHist);
     if (h->ws.digitTotal) (void)hipFree(h->ws.digitTotal);
-    if (h->cellRange) (void)hipFree(h->cellRange);
+    for (auto &t : h->cellTable) if (t) (void)hipFree(t);
     if (h->hostPos) (void)hipHostFree(h->hostPos);
     for (int b = 0; b < 2; ++b) {
         if (h->stage[b]) (void)hipHostFree(h->stage[b]);
@@ -1096,6 +1151,14 @@ int sph_phase_grid(sph_handle *h) {
     SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
+    if (h->gridAhead) { // built by the previous timed step for exactly this state
+        h->gridAhead = false;
+        // (a caller that does not go on with the build's events -- the phase API -- drops them: the
+        // density / force events of this entry would never be recorded)
+        if (h->aheadEv && h->curEv != h->aheadEv) h->aheadEv->used = false;
+        h->aheadEv = nullptr;
+        return SPH_OK;  // (phase is 1 already)
+    }
     if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "grid phase out of order");
     hipStream_t s = h->compute;
     StepEvents *ev = h->curEv;
@@ -1121,6 +1184,8 @@ int sph_phase_grid(sph_handle *h) {
     // kernelResetGrid (simulator.cu:321-326,492-495) and the cell hash are both part of the
     // first sort pass: no launch of their own
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
+    h->cellCur ^= 1; // the previous build's table stays intact (a click after a step pipelined ahead needs it)
+    h->cellRange = h->cellTable[h->cellCur];
     int res = sph_sort_cells(h->ws, h->P, h->pos4[c], n, key_bits(h), s, h->cellRange, h->P.numCells);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
     // the list sweeps take velocities from the interleaved records: no sorted vel4 copy
@@ -1170,6 +1235,8 @@ int sph_phase_force(sph_handle *h) {
     HIPCHK(h, hipGetLastError());
     h->cur = h->sorted ^ 1; // new state, still in this step's sorted order
     h->phase = 3;
+    h->clickTable = h->cellRange;
+    h->clickValid = h->opt.sweep != SPH_SWEEP_LINKED;
     return SPH_OK;
 }
 
@@ -1263,9 +1330,12 @@ int capture_step_graph(sph_handle *h, int slot) {
 
 int sph_step(sph_handle *h, SphTimes *times) {
     if (!h) return SPH_EINVAL;
+    const auto trIn = std::chrono::steady_clock::now();
+    if (h->trace && h->trSteps > 0) h->trBetween += std::chrono::duration<double>(trIn - h->trLastReturn).count();
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (!h->ready) return fail(h, SPH_ESTATE, "setup()/upload_state() must come first");
-    if (h->phase != 0 && h->phase != 3) return fail(h, SPH_ESTATE, "a step split into phases is still open");
+    if (h->phase != 0 && h->phase != 3 && !(h->gridAhead && h->phase == 1))
+        return fail(h, SPH_ESTATE, "a step split into phases is still open");
     int rc;
     // slot of the PREVIOUS step's position copy (if any)
     const int prevSlot = (int)((h->stepIndex + 1) & 1);
@@ -1274,6 +1344,7 @@ int sph_step(sph_handle *h, SphTimes *times) {
     const int slot = (int)(h->stepIndex & 1);
     bool viaGraph = false;
     if (h->useGraph && h->opt.sweep != SPH_SWEEP_LINKED && h->n > 0) {
+        drop_grid_ahead(h); // (never set in graph mode; belt and braces)
         if ((rc = fold_graph_events(h, slot))) return rc;
         if (!h->stepGraph[slot][2] && capture_step_graph(h, slot) != SPH_OK) h->useGraph = false;
         if (h->stepGraph[slot][2]) {
@@ -1310,17 +1381,54 @@ int sph_step(sph_handle *h, SphTimes *times) {
             }
         }
     }
+    auto trT = std::chrono::steady_clock::now();
+    auto trLap = [&](int k) {
+        if (!h->trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        h->trPh[k] += std::chrono::duration<double>(now - trT).count();
+        trT = now;
+    };
+    if (h->trace && !h->trBase && !viaGraph && !h->gridAhead) {
+        if (hipEventCreate(&h->trBase) == hipSuccess) (void)hipEventRecord(h->trBase, h->compute);
+    }
     if (!viaGraph) {
-        if ((rc = begin_step_events(h))) return rc;
-        ev = h->curEv;
-        if ((rc = sph_phase_grid(h))) return rc;
+        if (h->gridAhead) { // the previous timed step queued this step's grid build (and recorded its events)
+            ev = h->aheadEv;
+            h->curEv = ev;
+        } else {
+            if ((rc = begin_step_events(h))) return rc;
+            ev = h->curEv;
+        }
+        trLap(0);
+        if ((rc = sph_phase_grid(h))) return rc; // (a grid built ahead is consumed here)
+        trLap(1);
         if ((rc = sph_phase_density(h))) return rc;
+        trLap(2);
         if ((rc = sph_phase_force(h))) return rc;
+        trLap(3);
     }
     if ((rc = sph_phase_readback(h))) return rc; // ends the step
+    trLap(4);
     h->curEv = nullptr;
     if (times) {
-        HIPCHK(h, hipStreamSynchronize(h->compute));
+        const auto trA = std::chrono::steady_clock::now();
+        if (h->aheadEnabled && !viaGraph && !h->useGraph && h->opt.sweep != SPH_SWEEP_LINKED && h->n > 0) {
+            // queue the next step's grid build before waiting for this one (see sph_handle::gridAhead)
+            if ((rc = begin_step_events(h))) return rc;
+            StepEvents *nextEv = h->curEv;
+            if ((rc = sph_phase_grid(h))) return rc;
+            h->curEv = nullptr;
+            h->aheadEv = nextEv;
+            h->gridAhead = true;
+            HIPCHK(h, hipEventSynchronize(ev->e[5])); // this step's force sweep (not the grid queued behind it)
+        } else {
+            HIPCHK(h, hipStreamSynchronize(h->compute));
+        }
+        const auto trB = std::chrono::steady_clock::now();
+        if (h->trace) {
+            h->trEnqueue += std::chrono::duration<double>(trA - trIn).count();
+            h->trSync += std::chrono::duration<double>(trB - trA).count();
+        }
         report_oob(h);
         float gridMs = 0.f, sphMs = 0.f;
         HIPCHK(h, hipEventElapsedTime(&gridMs, ev->e[0], ev->e[3]));
@@ -1337,6 +1445,11 @@ int sph_step(sph_handle *h, SphTimes *times) {
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         times->iters += 1;
+        if (h->trace) {
+            h->trLastReturn = std::chrono::steady_clock::now();
+            h->trPost += std::chrono::duration<double>(h->trLastReturn - trB).count();
+            h->trSteps++;
+        }
     }
     return SPH_OK;
 }
@@ -1347,9 +1460,10 @@ int sph_apply_click(sph_handle *h, int mx, int my) {
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state): use the sph_slab_* entry points");
     if (h->opt.sweep == SPH_SWEEP_LINKED)
         return fail(h, SPH_ESTATE, "the click impulse is not available with SPH_SWEEP_LINKED");
-    if (!h->gridValid || h->phase != 0 || h->stepIndex == 0)
+    if (!h->clickValid || (h->phase != 0 && !h->gridAhead) || h->stepIndex == 0)
         return fail(h, SPH_ESTATE, "click needs a completed step (it reuses that step's grid)");
-    sph_launch_click(h->P, h->cellRange, h->vel4[h->cur], mx, my, h->compute);
+    drop_grid_ahead(h); // a grid built ahead gathered the velocities this impulse is about to change
+    sph_launch_click(h->P, h->clickTable, h->vel4[h->cur], mx, my, h->compute);
     HIPCHK(h, hipGetLastError());
     return SPH_OK;
 }
@@ -1381,7 +1495,7 @@ int sph_save_state(sph_handle *h, const char *path) {
     if (!h || !path) return SPH_EINVAL;
     SPH_ON_DEVICE(h);
     if (h->external) return fail(h, SPH_ESTATE, "handle is in slab mode (external state)");
-    if (!h->ready || h->phase != 0) return fail(h, SPH_ESTATE, "no complete state to save");
+    if (!h->ready || (h->phase != 0 && !h->gridAhead)) return fail(h, SPH_ESTATE, "no complete state to save");
     int rc = sph_sync(h);
     if (rc) return rc;
     const size_t n = (size_t)h->n;
@@ -1452,6 +1566,8 @@ int sph_load_state(sph_handle *h, const char *path) {
     }
     HIPCHK(h, hipDeviceSynchronize());
     drop_step_graphs(h);
+    drop_grid_ahead(h);
+    h->clickValid = false;
     h->ready = true;
     h->gridValid = false;
     h->phase = 0;
@@ -1549,8 +1665,10 @@ int sph_get_kernel_times(sph_handle *h, SphKernelTimes *out, int reset) {
     SPH_ON_DEVICE(h);
     int rc = sph_sync(h);
     if (rc) return rc;
-    for (auto &se : h->ring)
+    for (auto &se : h->ring) {
+        if (h->gridAhead && &se == h->aheadEv) continue; // a grid built ahead: its step has not run yet
         if ((rc = resolve_events(h, se))) return rc;
+    }
     for (int slot = 0; slot < 2; ++slot) {
         if (!h->graphEvPending[slot]) continue;
         h->graphEv[slot].used = true;

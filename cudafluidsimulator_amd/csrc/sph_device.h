@@ -103,6 +103,7 @@ struct GatherExtras {
     int cursorWords = 0;                  // ... this many 8-byte words
     int *bounds = nullptr;                // slab path: bounds[t] = #keys < thr.v[t], bounds[nthr] = n
     float4 *vref = nullptr;               // zero-pair filter: the most common velocity among 64 sampled rows goes here
+    uint32_t *quietAll = nullptr;         // single domain: the "every row is quiet" word is set to 1 here
     uint32_t *quietClear = nullptr;       // slab path: the filter's bit array is cleared here (halo rows stay "not quiet") ...
     int quietWords = 0;                   // ... this many 32-bit words
     Thresholds thr{};
@@ -171,6 +172,9 @@ struct SweepArgs {
                                       // has no pressure and moves with the reference velocity *quietVref; a hit between
                                       // two such rows adds exactly +-0 to the force and is dropped unread
     const float4 *quietVref;          // the reference velocity (picked by the gather launch of this step's grid build)
+    uint32_t *quietAll;               // single domain (else null): 1 while EVERY row of this step is quiet -- set by the
+                                      // gather launch, cleared by the density sweep's first non-quiet row; the force
+                                      // sweep then has no pair to evaluate and does not read its hit stream at all
     int rhoToVel4;                    // list sweep: also store rho in vel4.w (slab halo exchange B)
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
     const int *listHead;              // [numCells] first particle of the cell or -1

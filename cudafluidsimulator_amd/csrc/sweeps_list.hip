@@ -122,8 +122,11 @@ __device__ __forceinline__ void sl_store_quiet(const SweepArgs &A, int i, bool v
     const float4 vref = *A.quietVref;
     bool q = false;
     if (valid) q = sl_is_quiet(rho, A.pv8[2 * (size_t)i + 1], vref);
-    const unsigned long long qb = __ballot(q);
-    if (lane == 0) reinterpret_cast<unsigned long long *>(A.quiet)[(i - lane) >> 6] = qb;
+    const unsigned long long qb = __ballot(q), vb = __ballot(valid);
+    if (lane == 0) {
+        reinterpret_cast<unsigned long long *>(A.quiet)[(i - lane) >> 6] = qb;
+        if (A.quietAll && qb != vb) *A.quietAll = 0u; // (plain store: every writer writes the same value)
+    }
 }
 // quiet bits of rows [j, j + 32)
 __device__ __forceinline__ uint32_t sl_quiet_window(const uint32_t *__restrict__ quiet, uint32_t j) {
@@ -502,7 +505,10 @@ void k_force_list(DevParams P, SweepArgs A) {
     // handled by k_force_fallback (kept out of this kernel: its 27 table reads and
     // run arrays would cost two resident waves per SIMD here).
     if (baseq == SL_NONE) return;
-    {
+    // Every row of the domain quiet (fluid in free fall): no pair adds anything -- the hit stream is
+    // not even read, the sweep is the integration alone.
+    const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u;
+    if (!allQuiet) {
         // Bit cursor.  (jb, m): first candidate and remaining bits of the current
         // pair; (jq, mq): the pairs of the last quad loaded.  A lane's sequence ends
         // with a zero mask (or after Q quads).  pop() returns the next hit's sorted

@@ -628,3 +628,65 @@ def test_reference_settings_slim_equals_full_ieee(monkeypatch):
     for k in ("pos", "vel"):
         assert_bit_equal(out["slim"][k], out["ieee"][k], f"slim vs full IEEE: {k}")
         assert_bit_equal(out["slim"][k], out["direct"][k], f"list vs direct: {k}")
+
+
+# ---- timed steps queue the next step's grid build before they wait (sph_handle::gridAhead) ----
+
+def test_grid_built_ahead_survives_everything_that_can_happen_between_two_steps(tmp_path, monkeypatch):
+    """simulateAndTime() queues the NEXT step's grid build before it waits for its own step.  Whatever
+    comes between two steps must still see the state the finished step left, and the next step must be
+    the oracle's: a click (walks the finished step's cell table, kept in a second table, and drops the
+    grid built ahead -- it gathered velocities the impulse changes), getPosition(), download_state(), a
+    snapshot, the phase API, a plain simulate(), a re-upload; and SPH_PIPELINE=0 gives the same bits."""
+    pos, vel = random_state(30000, 31, lo=1.0, hi=9.0, vmax=0.3)
+
+    def run(pipeline):
+        monkeypatch.setenv("SPH_PIPELINE", pipeline)
+        sim, ref = make_pair(len(pos), False, pos=pos, vel=vel)
+        t = sph.Times()
+        sim.simulateAndTime(t); ref.step()
+        compare_state(sim, ref, "timed step 1")                       # state + getPosition with a grid ahead
+        sim.simulateAndTime(t); ref.step()
+        sim.moveParticles((420, 333)); ref.click(420, 333)            # click after a timed step
+        sim.moveParticles((300, 250)); ref.click(300, 250)            # ... and a second one
+        compare_state(sim, ref, "clicks after a timed step")
+        sim.simulateAndTime(t); ref.step()
+        snap = str(tmp_path / f"ahead{pipeline}.bin")
+        sim.save_state(snap)                                          # snapshot with a grid ahead
+        sim.simulate(); ref.step()                                    # untimed step consumes the grid ahead
+        for name in ("grid", "density", "force", "readback"):         # the phase API after it
+            sim.phase(name)
+        ref.step()
+        sim.simulateAndTime(t); ref.step()
+        for name in ("grid", "density", "force", "readback"):         # the phase API right after a timed step
+            sim.phase(name)
+        ref.step()
+        compare_state(sim, ref, "after phases")
+        g = sim.download_grid()                                       # (no grid ahead now: this step's grid)
+        assert np.array_equal(np.sort(g["ids"]), np.arange(len(pos), dtype=np.uint32))
+        sim.simulateAndTime(t); ref.step()
+        kt = sim.kernel_times()
+        assert kt.steps == 6 and t.iters == 5   # (steps driven through the phase API carry no events)
+        final = sim.download_state()
+        compare_state(sim, ref, "end")
+        # resume from the snapshot taken with a grid ahead: same continuation
+        sim.load_state(snap)
+        ref2 = O.OracleSim(len(pos), False)
+        ref2.upload(pos, vel)
+        for k in range(3):
+            ref2.step()
+            if k == 1:
+                ref2.click(420, 333); ref2.click(300, 250)
+        sim.simulateAndTime(t); ref2.step()
+        compare_state(sim, ref2, "resumed")
+        sim.upload_state(pos, vel)                                    # re-upload with a grid ahead
+        ref3 = O.OracleSim(len(pos), False)
+        ref3.upload(pos, vel)
+        sim.simulateAndTime(t); ref3.step()
+        compare_state(sim, ref3, "after a re-upload")
+        sim.close()
+        return final
+
+    a, b = run("1"), run("0")   # (30,000 particles: on by default; "1" also covers handles above the size threshold)
+    for k in ("pos", "vel", "rho"):
+        assert_bit_equal(a[k], b[k], f"pipelined vs not: {k}")
