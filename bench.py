@@ -327,6 +327,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_mgpu = bool(os.environ.get("SPH_BENCH_FORCE_MGPU"))  # tests: the N>1 code path with one rank
     if world > 1 or force_mgpu:
+        # The >= 2-rank RCCL path has never run on hardware: a rank that waits for ever
+        # in a receive must not hold the node -- give up loudly after ten minutes instead.
+        import signal
+
+        def _give_up(signum, frame):
+            sys.stderr.write("bench.py: multi-GPU run exceeded 600 s: giving up (a rank is waiting in an exchange?)\n")
+            sys.stderr.flush()
+            os._exit(3)
+        signal.signal(signal.SIGALRM, _give_up)
+        signal.alarm(600)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
