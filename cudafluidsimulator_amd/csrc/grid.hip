@@ -64,24 +64,6 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     if (i < X.cursorWords) X.cursor[i] = 0ull;
     if (i < X.quietWords) X.quietClear[i] = 0u;
     if (X.quietAll && i == 0) *X.quietAll = 1u;
-    // ... the force sweep's zero-pair filter gets its reference velocity: the most common one among
-    // 64 rows sampled evenly from the (unsorted) input -- a body of fluid in free fall shares one
-    // velocity bit for bit; any choice is correct, a popular one drops the most pairs ...
-    if (X.vref && blockIdx.x == 0 && threadIdx.x < SPH_WAVE) { // one wave, one sample per lane
-        const float4 v = vel_in[(long long)lane * n / SPH_WAVE];
-        int cnt = 0;
-        for (int k = 0; k < SPH_WAVE; ++k) { // (readlane: k is wave-uniform)
-            const float wx = __builtin_amdgcn_readlane(__float_as_int(v.x), k) == __float_as_int(v.x) ? 1.f : 0.f;
-            const bool same = wx != 0.f && __builtin_amdgcn_readlane(__float_as_int(v.y), k) == __float_as_int(v.y) &&
-                              __builtin_amdgcn_readlane(__float_as_int(v.z), k) == __float_as_int(v.z);
-            cnt += same ? 1 : 0;
-        }
-        // most matches, then the lowest sample: wave-wide max of cnt * 64 + (63 - lane)
-        int best = cnt * SPH_WAVE + (SPH_WAVE - 1 - lane);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
-        if (best == cnt * SPH_WAVE + (SPH_WAVE - 1 - lane)) *X.vref = v;
-    }
     bool valid = i < n;
     uint32_t k = valid ? skeys[i] : 0xFFFFFFFFu;
     uint32_t kprev = __shfl_up(k, 1);
@@ -92,6 +74,13 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     if (i + 1 >= n) knext = 0xFFFFFFFFu;
     uint32_t src = perm[i];
     const float4 p = pos_in[src], v = vel_in[src];
+    // ... and the zero-pair filter's "moves with the reference velocity" bit of every row (the reference was
+    // picked by the first sort pass of this build); one 64-bit word per 64 rows
+    if (X.calm) {
+        const float4 vr = *X.vref;
+        const unsigned long long cb = __ballot(v.x == vr.x && v.y == vr.y && v.z == vr.z);
+        if (lane == 0) X.calm[i >> 6] = cb;
+    }
     pos_out[i] = p;
     if (vel_out) vel_out[i] = v; // (null: the list sweeps read velocities from pv8 only)
     if (pv8) { // interleaved copy for the list sweep's force gathers (one line per hit)

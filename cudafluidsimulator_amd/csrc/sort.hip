@@ -89,7 +89,8 @@ template <int BITS, bool HASH, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS *RS_ITEMS / RS_HIST_ITEMS) void k_radix_hist(
     const uint32_t *__restrict__ keys, uint32_t *__restrict__ blockHist, int n,
     int shift, int numBlocks, DevParams P, const float4 *__restrict__ pos4,
-    uint32_t *__restrict__ keysOut, int2 *__restrict__ zeroTable, int zeroCount, SphOobLog *oob) {
+    uint32_t *__restrict__ keysOut, int2 *__restrict__ zeroTable, int zeroCount, SphOobLog *oob,
+    const float4 *__restrict__ velSample, float4 *__restrict__ vrefOut) {
     constexpr int DIG = 1 << BITS;
     constexpr int HT = RS_THREADS * RS_ITEMS / RS_HIST_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS;
     constexpr int WAVE_KEYS = SPH_WAVE * RS_HIST_ITEMS;
@@ -99,6 +100,24 @@ __global__ __launch_bounds__(RS_THREADS *RS_ITEMS / RS_HIST_ITEMS) void k_radix_
     if (HASH) // kernelResetGrid (simulator.cu:321-326): the cell table is cleared here, not by a launch of its own
         for (int k = blockIdx.x * HT + t; k < zeroCount; k += numBlocks * HT)
             zeroTable[k] = make_int2(0, 0);
+    // rider of the grid build's first pass: the reference velocity of the force sweep's zero-pair filter = the
+    // most common velocity among 64 rows sampled evenly from the (unsorted) input -- a body of fluid in free fall
+    // shares one velocity bit for bit; any choice is correct, a popular one drops the most pairs
+    if (HASH && velSample && blockIdx.x == 0 && t < SPH_WAVE) {
+        const float4 v = velSample[(long long)lane * n / SPH_WAVE];
+        int cnt = 0;
+        for (int k = 0; k < SPH_WAVE; ++k) { // (readlane: k is wave-uniform)
+            const bool same = __builtin_amdgcn_readlane(__float_as_int(v.x), k) == __float_as_int(v.x) &&
+                              __builtin_amdgcn_readlane(__float_as_int(v.y), k) == __float_as_int(v.y) &&
+                              __builtin_amdgcn_readlane(__float_as_int(v.z), k) == __float_as_int(v.z);
+            cnt += same ? 1 : 0;
+        }
+        // most matches, then the lowest sample: wave-wide max of cnt * 64 + (63 - lane)
+        int best = cnt * SPH_WAVE + (SPH_WAVE - 1 - lane);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if (best == cnt * SPH_WAVE + (SPH_WAVE - 1 - lane)) *vrefOut = v;
+    }
     __syncthreads();
     // a wave owns WAVE_KEYS consecutive keys, RS_HIST_ITEMS rounds of 64
     const long long base = (long long)blockIdx.x * RS_TILE + (long long)w * WAVE_KEYS + lane;
@@ -287,7 +306,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
     if (pos4) { // first pass of the grid build: hash fused in, values = iota
         k_radix_hist<BITS, true, ITEMS><<<numBlocks, RS_THREADS * ITEMS / RS_HIST_ITEMS, 0, s>>>(nullptr, ws.blockHist, n, shift,
                                                                          numBlocks, *P, pos4, ws.keys[cur],
-                                                                         zeroTable, zeroCount, ws.oob);
+                                                                         zeroTable, zeroCount, ws.oob, ws.velSample, ws.vrefOut);
         k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
         k_radix_scatter<BITS, true, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
             ws.keys[cur], nullptr, ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist, ws.digitTotal, n, shift,
@@ -295,7 +314,7 @@ static void radix_pass(const SortWorkspace &ws, int cur, int n, int shift, hipSt
         return;
     }
     k_radix_hist<BITS, false, ITEMS><<<numBlocks, RS_THREADS * ITEMS / RS_HIST_ITEMS, 0, s>>>(ws.keys[cur], ws.blockHist, n, shift,
-                                                                      numBlocks, DevParams{}, nullptr, nullptr, nullptr, 0, nullptr);
+                                                                      numBlocks, DevParams{}, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     k_radix_rowscan<<<1 << BITS, RS_THREADS, 0, s>>>(ws.blockHist, ws.digitTotal, numBlocks);
     k_radix_scatter<BITS, false, ITEMS><<<numBlocks, RS_THREADS, 0, s>>>(
         ws.keys[cur], ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], ws.blockHist,

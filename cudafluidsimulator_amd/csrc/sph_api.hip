@@ -122,7 +122,8 @@ struct sph_handle {
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
-    float4 *quietVref = nullptr;     // ... and its reference velocity (device; written by the gather launch)
+    float4 *quietVref = nullptr;     // ... its reference velocity (device; picked by the first sort pass) ...
+    unsigned long long *calm = nullptr; // ... and one bit per sorted row "moves with it" (written by the gather launch)
     float4 *initPos4 = nullptr;      // setup()'s initial positions (+ids), kept on the device for the next setup()
     SphOobLog *oobHost = nullptr;    // host-mapped: positions outside the grid met by the cell hash
     uint32_t oobSeen = 0;            // how many of them were already reported
@@ -385,6 +386,8 @@ int alloc_device(sph_handle *h) {
         HIPCHK(h, hipMemset(h->quiet, 0, quietWords * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->quietVref, 2 * sizeof(float4))); // [0] the reference velocity, [1].x the all-quiet word
         HIPCHK(h, hipMemset(h->quietVref, 0, 2 * sizeof(float4)));
+        HIPCHK(h, hipMalloc(&h->calm, ((cap + 63) / 64 + 1) * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->calm, 0, ((cap + 63) / 64 + 1) * sizeof(unsigned long long)));
         if (const char *e = getenv("SPH_ZERO_PAIR_FILTER")) h->useQuiet = atoi(e) != 0;
     }
     HIPCHK(h, hipHostMalloc(&h->oobHost, sizeof(SphOobLog), hipHostMallocMapped));
@@ -690,7 +693,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     // (slabs: the wave origin is rounded down to a multiple of 64, the gather launch clears the array,
     // so halo rows -- whose densities arrive after the density sweep -- stay "not quiet")
     A.quiet = (h->useQuiet && h->quiet) ? h->quiet : nullptr;
-    A.quietVref = h->quietVref;
+    A.calm = h->calm;
     A.quietAll = (A.quiet && !h->external) ? reinterpret_cast<uint32_t *>(h->quietVref + 1) : nullptr;
     A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
@@ -708,6 +711,7 @@ GatherExtras gather_extras(sph_handle *h) {
     }
     if (h->quiet && h->useQuiet) {
         X.vref = h->quietVref;
+        X.calm = h->calm;
         if (!h->external) X.quietAll = reinterpret_cast<uint32_t *>(h->quietVref + 1);
         if (h->external) { // single domain: the density sweep rewrites every word each step
             X.quietClear = h->quiet;
@@ -804,6 +808,8 @@ int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
     hipStream_t s = h->compute;
     PairEvent *pe = nullptr;
     if ((rc = pair_begin(h, &h->kt.sort, &pe))) return rc;
+    h->ws.velSample = (h->quiet && h->useQuiet) ? h->vel4[src_buf] + src_offset : nullptr; // the filter's reference velocity
+    h->ws.vrefOut = h->quietVref;
     int res = sph_sort_cells(h->ws, h->P, h->pos4[src_buf] + src_offset, count, key_bits(h), s, h->cellRange,
                              h->P.numCells); // (clears the cell table too)
     // the segment bounds (and the element count, [nthr]) and the clearing of the hit-stream
@@ -1201,6 +1207,7 @@ void sph_destroy(sph_handle *h) {
     if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->quiet) (void)hipFree(h->quiet);
     if (h->quietVref) (void)hipFree(h->quietVref);
+    if (h->calm) (void)hipFree(h->calm);
     if (h->initPos4) (void)hipFree(h->initPos4);
     if (h->oobHost) (void)hipHostFree(h->oobHost);
     if (h->boundsDev) (void)hipFree(h->boundsDev);
@@ -1301,6 +1308,8 @@ int sph_phase_grid(sph_handle *h) {
     if (ev) HIPCHK(h, hipEventRecord(ev->e[1], s));
     h->cellCur ^= 1; // the previous build's table stays intact (a click after a step pipelined ahead needs it)
     h->cellRange = h->cellTable[h->cellCur];
+    h->ws.velSample = (h->quiet && h->useQuiet) ? h->vel4[c] : nullptr; // the zero-pair filter's reference velocity
+    h->ws.vrefOut = h->quietVref;
     int res = sph_sort_cells(h->ws, h->P, h->pos4[c], n, key_bits(h), s, h->cellRange, h->P.numCells);
     if (ev) HIPCHK(h, hipEventRecord(ev->e[2], s));
     // the list sweeps take velocities from the interleaved records: no sorted vel4 copy

@@ -80,6 +80,10 @@ struct SortWorkspace {
     int capacity;         // elements
     int maxBlocks;
     SphOobLog *oob;       // device view of the handle's out-of-grid log (may be null)
+    // zero-pair filter (optional): the first pass of a grid build samples 64 rows of velSample[0..n) and leaves the
+    // most common velocity in *vrefOut -- the gather launch of the same build marks the rows that move with it
+    const float4 *velSample;
+    float4 *vrefOut;
 };
 size_t sph_sort_workspace_blocks(int n);
 // Stable LSD sort of (keys[0], vals[0]) on `bits` key bits; returns the index
@@ -102,7 +106,8 @@ struct GatherExtras {
     unsigned long long *cursor = nullptr; // hit-stream allocation cursors to clear ...
     int cursorWords = 0;                  // ... this many 8-byte words
     int *bounds = nullptr;                // slab path: bounds[t] = #keys < thr.v[t], bounds[nthr] = n
-    float4 *vref = nullptr;               // zero-pair filter: the most common velocity among 64 sampled rows goes here
+    const float4 *vref = nullptr;         // zero-pair filter: the reference velocity (picked by the first sort pass) ...
+    unsigned long long *calm = nullptr;   // ... and one bit per sorted row "moves with it", a 64-bit word per 64 rows
     uint32_t *quietAll = nullptr;         // single domain: the "every row is quiet" word is set to 1 here
     uint32_t *quietClear = nullptr;       // slab path: the filter's bit array is cleared here (halo rows stay "not quiet") ...
     int quietWords = 0;                   // ... this many 32-bit words
@@ -171,7 +176,7 @@ struct SweepArgs {
     uint32_t *quiet;                  // zero-pair filter (may be null = off): bit j of this array is set when sorted row j
                                       // has no pressure and moves with the reference velocity *quietVref; a hit between
                                       // two such rows adds exactly +-0 to the force and is dropped unread
-    const float4 *quietVref;          // the reference velocity (picked by the gather launch of this step's grid build)
+    const unsigned long long *calm;   // bit j: sorted row j moves with the reference velocity (written by the gather launch)
     uint32_t *quietAll;               // single domain (else null): 1 while EVERY row of this step is quiet -- set by the
                                       // gather launch, cleared by the density sweep's first non-quiet row; the force
                                       // sweep then has no pair to evaluate and does not read its hit stream at all

@@ -108,20 +108,18 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 // reading j at all.  That is every pair of a body of fluid in free fall -- all of the
 // reference's `-i random` run until the cloud reaches the floor, and the part of it still
 // falling afterwards.  The density sweep leaves one bit per sorted row: "no pressure, and the
-// velocity equals the reference velocity" (any reference is correct; the gather launch picks the
-// most common velocity among 64 sampled rows -- the last sorted row, the top of the highest
-// z-layer, was the first choice and went wrong at step 57 of the headline run, when splashes from
-// the floor opened a z-layer of their own); the force sweep of a quiet row clears the quiet
-// candidates out of its hit masks, 32 at a time.
-__device__ __forceinline__ bool sl_is_quiet(float rho, const float4 &v, const float4 &vref) {
-    const float prs = fmaxf(0.f, SPH_GAS_CONSTANT * (rho - SPH_REST_DENSITY));
-    return prs == 0.f && v.x == vref.x && v.y == vref.y && v.z == vref.z;
-}
-// one 64-bit word per 64-row wave (rows [i - lane, i - lane + 64), i - lane a multiple of 64)
+// velocity equals the reference velocity" (any reference is correct; the first sort pass picks the
+// most common velocity among 64 sampled rows and the gather launch compares every row with it --
+// the last sorted row, the top of the highest z-layer, was the first choice and went wrong at step
+// 57 of the headline run, when splashes from the floor opened a z-layer of their own); the force
+// sweep of a quiet row clears the quiet candidates out of its hit masks, 32 at a time.
+// one 64-bit word per 64-row wave (rows [i - lane, i - lane + 64), i - lane a multiple of 64); the gather
+// launch left the velocity half of the test ("calm": the row moves with the reference velocity) as a word of
+// the same shape, so the sweep adds the pressure half without reading a velocity
 __device__ __forceinline__ void sl_store_quiet(const SweepArgs &A, int i, bool valid, float rho, int lane) {
-    const float4 vref = *A.quietVref;
-    bool q = false;
-    if (valid) q = sl_is_quiet(rho, A.pv8[2 * (size_t)i + 1], vref);
+    const unsigned long long calm = A.calm[(i - lane) >> 6]; // (wave-uniform address)
+    const float prs = fmaxf(0.f, SPH_GAS_CONSTANT * (rho - SPH_REST_DENSITY));
+    const bool q = valid && prs == 0.f && ((calm >> lane) & 1ull);
     const unsigned long long qb = __ballot(q), vb = __ballot(valid);
     if (lane == 0) {
         reinterpret_cast<unsigned long long *>(A.quiet)[(i - lane) >> 6] = qb;
