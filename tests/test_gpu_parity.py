@@ -690,3 +690,25 @@ def test_grid_built_ahead_survives_everything_that_can_happen_between_two_steps(
     a, b = run("1"), run("0")   # (30,000 particles: on by default; "1" also covers handles above the size threshold)
     for k in ("pos", "vel", "rho"):
         assert_bit_equal(a[k], b[k], f"pipelined vs not: {k}")
+
+
+@pytest.mark.parametrize("n", [100000, 2000000])
+def test_timed_and_untimed_steps_mixed_read_back_paths(n):
+    """Timed steps read their positions back through an SDMA engine (issued by the host once it has seen
+    the force sweep finish), untimed ones through the stream-ordered HIP copy; both land in the one host
+    buffer getPosition() returns.  Any mix of the two, with and without getPosition() in between, shows
+    the oracle's positions after every step (n = 2,000,000: the copies are long enough to overlap)."""
+    sim, ref = make_pair(n, True)
+    t = sph.Times()
+    pattern = "TTUUTUTTTUUUTTUT"
+    for k, c in enumerate(pattern, 1):
+        if c == "T":
+            sim.simulateAndTime(t)
+        else:
+            sim.simulate()
+        ref.step()
+        if k % 3 != 0:   # (every third step nobody looks: the next copy must still wait for this one)
+            assert_bit_equal(np.array(sim.getPosition()), ref.download()["pos"], f"step {k} ({c})")
+    compare_state(sim, ref, "end of the mixed run")
+    assert t.iters == pattern.count("T") and sim.kernel_times().readback > 0
+    sim.close()
