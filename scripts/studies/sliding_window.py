@@ -6,7 +6,10 @@ pos, vel, rho): per sampled wave of 64 consecutive sorted particles, every lane'
   shipped : records [w0, w0 + 160) around the wave's own particles
   sliding : records [ws, ws + W); whenever fewer than `thr` of the live lanes find their hit inside, the
             window is re-staged at the q-quantile of the live lanes' current indices
-usage: python scripts/studies/sliding_window.py state.npz [waves] [min cell occupancy]"""
+usage: python scripts/studies/sliding_window.py state.npz [waves] [min cell occupancy] [subcells per axis]
+  subcells per axis S > 1: particles inside a cell ordered by an S x S x S sub-cell index (x fastest) -- what a
+  sub-cell key order would give: lanes of a wave spatially coherent.  Also printed: lane efficiency (mean / max
+  hits per wave) and distinct 128-byte lines per trip among the lanes outside the shipped window."""
 import sys
 import numpy as np
 
@@ -14,11 +17,17 @@ D, H = 100, np.float32(0.1)
 z = np.load(sys.argv[1])
 nw = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 minocc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+SUB = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 pos, vel, rho = z["pos"], z["vel"], z["rho"]
 n = len(pos)
 c = np.clip((pos / H).astype(np.int64), 0, D - 1)
 key = c[:, 0] + D * c[:, 1] + D * D * c[:, 2]
+if SUB > 1:
+    f = np.clip(((pos / H - c) * SUB).astype(np.int64), 0, SUB - 1)
+    key = key * (SUB ** 3) + f[:, 0] + SUB * f[:, 1] + SUB * SUB * f[:, 2]
 order = np.argsort(key, kind="stable")
+if SUB > 1:
+    key = key // (SUB ** 3)
 pos, vel, rho, key, c = pos[order], vel[order], rho[order], key[order], c[order]
 start = np.searchsorted(key, np.arange(D ** 3), side="left")
 end = np.searchsorted(key, np.arange(D ** 3), side="right")
@@ -57,6 +66,8 @@ configs = [("shipped 160", None), ("sliding W=160 thr=1/2 q=0.25", (160, 0.5, 0.
            ("sliding W=160 thr=1/4 q=0.1", (160, 0.25, 0.1)), ("sliding W=256 thr=1/4 q=0.25", (256, 0.25, 0.25)),
            ("sliding W=96 thr=1/4 q=0.25", (96, 0.25, 0.25))]
 tot = {k: [0, 0, 0, 0] for k, _ in configs}   # hits, served, restages, trips
+eff = [0, 0]      # sum of mean hits, sum of max hits
+lines = [0, 0]    # distinct lines among out-of-window lanes, trips
 for w in waves:
     L = hit_lists(w)
     T = max(len(x) for x in L)
@@ -66,6 +77,14 @@ for w in waves:
     for l, x in enumerate(L):
         J[l, :len(x)] = x
     live = J >= 0
+    eff[0] += live.sum() / 64.0
+    eff[1] += T
+    w0_ = max(w * 64 - 48, 0)
+    for t in range(0, T, 7):
+        jl = J[live[:, t], t]
+        jl = jl[(jl < w0_) | (jl >= w0_ + 160)]
+        lines[0] += len(np.unique(jl // 4))
+        lines[1] += 1
     for name, cfg in configs:
         if cfg is None:
             w0 = max(w * 64 - 48, 0)
@@ -84,7 +103,9 @@ for w in waves:
                 served += int(inw.sum())
         a = tot[name]
         a[0] += int(live.sum()); a[1] += int(served); a[2] += rest; a[3] += T
-print(f"{sys.argv[1]}: {len(waves)} waves" + (f" starting in cells of >= {minocc}" if minocc else ""))
+print(f"{sys.argv[1]}: {len(waves)} waves" + (f" starting in cells of >= {minocc}" if minocc else "") +
+      (f", particles ordered by {SUB}^3 sub-cells inside a cell" if SUB > 1 else "") +
+      f"; lane efficiency {eff[0]/max(eff[1],1):.3f}; distinct lines per trip outside the window {lines[0]/max(lines[1],1):.1f}")
 for name, _ in configs:
     h, s, r, t = tot[name]
     print(f"  {name:32s}: served from LDS {100*s/max(h,1):5.1f} % of {h/len(waves):7.0f} pair bodies per wave; "
