@@ -420,12 +420,15 @@ def main():
             # one-line legs for the other single-GPU configurations of BASELINE.json (defaults only)
             if n == 4194304 and random_init and args.sweep == "list" and args.math == "strict":
                 legs = {}
-                for name, (ln, lk, lw) in {"config2_n262144_100steps": (262144, 100, 5),
-                                           "config4_n16777216_single_gpu_10steps": (16777216, 10, 2)}.items():
-                    ls = sph.default_settings(ln, True)
-                    lr = timed_run(sph, _lib, torch, ls, args, lk, lw, local_rank, settle=RUNTIME_SETTLE_STEPS)
-                    legs[name] = {"workload": f"-n {ln} -i random -m time, first {lk} steps" if lk != 100 else
-                                  f"-n {ln} -i random -m time (100 steps)",
+                for name, (ln, lk, lw, lrand, lsettle) in {
+                        "config2_n262144_100steps": (262144, 100, 5, True, RUNTIME_SETTLE_STEPS),
+                        "config4_n16777216_single_gpu_10steps": (16777216, 10, 2, True, RUNTIME_SETTLE_STEPS),
+                        "config5_n67108864_grid_single_gpu_3steps": (67108864, 3, 1, False, 0)}.items():
+                    ls = sph.default_settings(ln, lrand)
+                    lr = timed_run(sph, _lib, torch, ls, args, lk, lw, local_rank, settle=lsettle)
+                    init_name = "random" if lrand else "grid (dense-lattice extension beyond 109^3, DESIGN.md section 8)"
+                    legs[name] = {"workload": f"-n {ln} -i {init_name} -m time, first {lk} steps" if lk != 100 else
+                                  f"-n {ln} -i {init_name} -m time (100 steps)",
                                   "value": ln * lk / lr["elapsed"], "unit": "particle-steps/s",
                                   "ms_per_step": lr["elapsed"] / lk * 1e3, "steps": lk, "warmup": lw,
                                   "kernel_ms_per_step": kernel_ms(lr["kt"])}

@@ -109,6 +109,7 @@ struct sph_handle {
     hsa_signal_t rbSig[2]{};
     bool rbPending[2] = {false, false};
     int rbDeferredSlot = -1;         // the read-back phase left this slot's copy to sph_step
+    uint32_t sdmaEngine = 0;         // hsa_amd_sdma_engine_id_t picked by sdma_init (0: the HSA runtime's own choice)
     double hsaTickSeconds = 0;
     bool cursorClean = false; // the gather launch of this grid build cleared the hit-stream cursors
     long long stepIndex = 0;
@@ -545,7 +546,49 @@ void sdma_init(sph_handle *h) {
     h->hsaGpu = S.gpu;
     h->hsaCpu = S.cpu;
     h->hsaTickSeconds = 1.0 / (double)hz;
+    // The engines are not alike: on an MI355X four of them move 56 GB/s to the host and the rest 12.8
+    // (scripts/microbench/sdma_d2h.cpp), and left to itself the HSA runtime sometimes hands out a slow one.
+    // Time a few megabytes through every free engine once and keep the fastest.
+    const size_t probe = std::min<size_t>((size_t)h->n * 3 * sizeof(float), (size_t)4 << 20);
+    auto time_engine = [&](uint32_t engine) -> double { // seconds, or < 0
+        double best = -1;
+        for (int rep = 0; rep < 2; ++rep) {
+            hsa_signal_store_relaxed(h->rbSig[0], 1);
+            const hsa_status_t st = engine
+                ? hsa_amd_memory_async_copy_on_engine(h->hostPos, S.cpu, h->devPos[0], S.gpu, probe, 0, nullptr, h->rbSig[0],
+                                                      (hsa_amd_sdma_engine_id_t)engine, false)
+                : hsa_amd_memory_async_copy(h->hostPos, S.cpu, h->devPos[0], S.gpu, probe, 0, nullptr, h->rbSig[0]);
+            if (st != HSA_STATUS_SUCCESS) return -1;
+            int tries = 0;
+            while (hsa_signal_wait_scacquire(h->rbSig[0], HSA_SIGNAL_CONDITION_LT, 1, hz / 2, HSA_WAIT_STATE_BLOCKED) >= 1)
+                if (++tries > 20) return -1;
+            hsa_amd_profiling_async_copy_time_t t{};
+            if (hsa_amd_profiling_get_async_copy_time(h->rbSig[0], &t) != HSA_STATUS_SUCCESS || t.end <= t.start) return -1;
+            const double sec = (double)(t.end - t.start) * h->hsaTickSeconds;
+            if (best < 0 || sec < best) best = sec;
+        }
+        return best;
+    };
+    if (probe >= ((size_t)1 << 16)) {
+        double bestSec = time_engine(0);
+        uint32_t mask = 0;
+        if (hsa_amd_memory_copy_engine_status(S.cpu, S.gpu, &mask) == HSA_STATUS_SUCCESS)
+            for (uint32_t bit = 1; bit && bit <= mask; bit <<= 1) {
+                if (!(mask & bit)) continue;
+                const double sec = time_engine(bit);
+                if (sec > 0 && (bestSec < 0 || sec < 0.9 * bestSec)) { bestSec = sec; h->sdmaEngine = bit; }
+            }
+        if (bestSec < 0) { // no engine moved the probe: leave the read-back to the HIP runtime
+            (void)hsa_signal_destroy(h->rbSig[0]);
+            (void)hsa_signal_destroy(h->rbSig[1]);
+            h->hsaTickSeconds = 0;
+            (void)hsa_shut_down();
+            return;
+        }
+        memset(h->hostPos, 0, probe);
+    }
     h->sdmaOk = true;
+    if (getenv("SPH_STEP_TRACE")) fprintf(stderr, "sph: read-back through SDMA engine id 0x%x (0 = the HSA runtime's choice)\n", h->sdmaEngine);
 }
 
 // wait for the SDMA copy out of devPos[slot] (if one is in flight); its duration goes to kt.readback
@@ -575,8 +618,15 @@ int sdma_issue(sph_handle *h, int slot) {
     hsa_signal_t dep = h->rbSig[slot ^ 1];
     const bool haveDep = h->rbPending[slot ^ 1]; // copies land in one host buffer: one after the other
     hsa_signal_store_relaxed(h->rbSig[slot], 1);
-    if (hsa_amd_memory_async_copy(h->hostPos, h->hsaCpu, h->devPos[slot], h->hsaGpu, (size_t)h->n * 3 * sizeof(float),
-                                  haveDep ? 1 : 0, haveDep ? &dep : nullptr, h->rbSig[slot]) != HSA_STATUS_SUCCESS) {
+    const size_t bytes = (size_t)h->n * 3 * sizeof(float);
+    hsa_status_t st = HSA_STATUS_ERROR;
+    if (h->sdmaEngine)
+        st = hsa_amd_memory_async_copy_on_engine(h->hostPos, h->hsaCpu, h->devPos[slot], h->hsaGpu, bytes, haveDep ? 1 : 0,
+                                                 haveDep ? &dep : nullptr, h->rbSig[slot], (hsa_amd_sdma_engine_id_t)h->sdmaEngine, false);
+    if (st != HSA_STATUS_SUCCESS) // (no engine picked, or it is busy: the HSA runtime's own choice)
+        st = hsa_amd_memory_async_copy(h->hostPos, h->hsaCpu, h->devPos[slot], h->hsaGpu, bytes, haveDep ? 1 : 0,
+                                       haveDep ? &dep : nullptr, h->rbSig[slot]);
+    if (st != HSA_STATUS_SUCCESS) {
         h->sdmaOk = false; // fall back to the runtime's copy, now and from here on
         rc = sdma_wait(h, slot ^ 1);
         if (rc) return rc;
