@@ -1086,7 +1086,7 @@ int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, 
 }
 
 const char *sph_build_info(void) {
-    return "libsph_hip gfx950 (MI355X/CDNA4), api v1, strict-fp32 sweeps, "
+    return "libsph_hip gfx950 (MI355X/CDNA4), api v2, strict-fp32 sweeps, "
            "8/10-bit LSD radix grid build";
 }
 

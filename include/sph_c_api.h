@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SPH_API_VERSION 1
+#define SPH_API_VERSION 2 /* 2: + sph_slab_apply_click, sph_slab_records (additive; every v1 entry point unchanged) */
 
 #define SPH_OK 0
 #define SPH_EINVAL (-1)  /* bad argument / state outside the box       */
