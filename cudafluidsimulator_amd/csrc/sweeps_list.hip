@@ -223,7 +223,11 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
                 pm0 = mask;
                 pending = true;
             } else {
+#if defined(SL_DBG_SAMEADDR) // (perf-only experiments: what the hit stream's stores cost the density sweep)
+                myq[0] = make_uint4(pj0, pm0, jbase, mask);
+#elif !defined(SL_DBG_NOEMIT)
                 myq[(size_t)qidx * SPH_WAVE] = make_uint4(pj0, pm0, jbase, mask);
+#endif
                 ++qidx;
                 pending = false;
             }

@@ -19,11 +19,12 @@ ap.add_argument("--every", type=int, default=5)
 ap.add_argument("--count", action="store_true")
 ap.add_argument("--math", default="strict")
 ap.add_argument("--init", default="random")
+ap.add_argument("--sweep", default="list")
 args = ap.parse_args()
 
 s = sph.default_settings(args.n, args.init == "random")
 flags = _lib.SPH_FLAG_COUNT_PAIRS if args.count else 0
-sim = sph.Simulator(s, flags=flags, math=args.math)
+sim = sph.Simulator(s, flags=flags, math=args.math, sweep=args.sweep)
 sim.setup()
 t = sph.Times()
 for _ in range(12):  # runtime settle (bench.py)
