@@ -122,6 +122,7 @@ struct sph_handle {
     SphKernelTimes kt{};
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
+    uint32_t *hitCount = nullptr;    // SPH_SWEEP_LIST: recorded hits per sorted row
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
     float4 *quietVref = nullptr;     // ... its reference velocity (device; picked by the first sort pass) ...
     unsigned long long *calm = nullptr; // ... and one bit per sorted row "moves with it" (written by the gather launch)
@@ -381,6 +382,8 @@ int alloc_device(sph_handle *h) {
         HIPCHK(h, hipMemset(h->maskOff, 0xFF, hdrWords * sizeof(uint32_t)));
         HIPCHK(h, hipMalloc(&h->maskCursor, kCursorBytes));
         HIPCHK(h, hipMemset(h->maskCursor, 0, kCursorBytes));
+        HIPCHK(h, hipMalloc(&h->hitCount, (cap + 64) * sizeof(uint32_t)));
+        HIPCHK(h, hipMemset(h->hitCount, 0, (cap + 64) * sizeof(uint32_t)));
         // one bit per sorted row + the word a 32-row window may reach into
         const size_t quietWords = 2 * ((cap + 63) / 64) + 2;
         HIPCHK(h, hipMalloc(&h->quiet, quietWords * sizeof(uint32_t)));
@@ -737,6 +740,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.tileRotate = h->tileRotate;
     A.maskPool = h->maskPool;
     A.maskOff = h->maskOff;
+    A.hitCount = h->hitCount;
     A.maskCursor = h->maskCursor;
     A.maskCapacity = h->maskCapacity;
     A.pv8 = h->pv8;
@@ -1254,6 +1258,7 @@ void sph_destroy(sph_handle *h) {
     if (h->pv8) (void)hipFree(h->pv8);
     if (h->maskPool) (void)hipFree(h->maskPool);
     if (h->maskOff) (void)hipFree(h->maskOff);
+    if (h->hitCount) (void)hipFree(h->hitCount);
     if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->quiet) (void)hipFree(h->quiet);
     if (h->quietVref) (void)hipFree(h->quietVref);
