@@ -554,6 +554,10 @@ void k_force_list(DevParams P, SweepArgs A) {
     // (one window per workgroup: the records around its SL_K2_THREADS rows)
 #define SL_WG_WINDOW (SL_K2_THREADS + SL_WINDOW - SPH_WAVE)
     __shared__ float4 win[2 * SL_WG_WINDOW];
+#ifdef SL_PAD_LDS // (perf experiment: fewer resident workgroups per CU, nothing else changed)
+    __shared__ float padLds[SL_PAD_LDS / 4];
+    if (A.n_all < 0) padLds[threadIdx.x] = 1.f, pi.x = padLds[threadIdx.x ^ 1];
+#endif
     const int w0 = max(R0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WG_WINDOW, A.n_all - w0), 0);
 #else
@@ -726,10 +730,26 @@ void k_force_list(DevParams P, SweepArgs A) {
         // fetch: issue the global gather only for lanes whose hit is outside the
         // window (fewer active lanes = fewer addresses for the TA); the LDS copy is
         // read when the hit is consumed.
+        // (a lane's record comes EITHER from the gather or from the window: the registers are declared
+        // undefined before the gather, or the compiler keeps "the old value where no load was issued" alive
+        // through both conditionals -- 14 v_mov per pair body and a second set of record registers)
+#if defined(SL_GATHER_NT) // (perf experiment: cache policy of the gathers)
+typedef float sl_f4 __attribute__((ext_vector_type(4)));
+#define SL_GLOAD(ptr) ([&]() { const sl_f4 t_ = __builtin_nontemporal_load(reinterpret_cast<const sl_f4 *>(ptr)); return make_float4(t_.x, t_.y, t_.z, t_.w); }())
+#else
+#define SL_GLOAD(ptr) (*(ptr))
+#endif
+#ifndef SL_NO_UNDEF
+#define SL_UNDEF4(q) asm volatile("" : "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w));
+#else
+#define SL_UNDEF4(q)
+#endif
 #define SL_FETCH(j, p, v)                                                      \
+    SL_UNDEF4(p)                                                               \
+    SL_UNDEF4(v)                                                               \
     if ((unsigned)((j)-w0) >= (unsigned)wlen) {                                \
-        p = A.pv8[2 * (size_t)(j)];                                            \
-        v = A.pv8[2 * (size_t)(j) + 1];                                        \
+        p = SL_GLOAD(A.pv8 + 2 * (size_t)(j));                                 \
+        v = SL_GLOAD(A.pv8 + 2 * (size_t)(j) + 1);                             \
     }
 #define SL_USE(j, p, v)                                                        \
     if ((unsigned)((j)-w0) < (unsigned)wlen) {                                 \
@@ -748,16 +768,32 @@ void k_force_list(DevParams P, SweepArgs A) {
         SL_FETCH(j0, p0, v0)
         int j1 = pop();
         SL_FETCH(j1, p1, v1)
+        // (`live` after a pop: some lane has a hit beyond the ones popped so far.  An exhausted lane pops itself:
+        // dist = 0, an exact no-op -- so the exit test is made once per two bodies, at the price of at most two
+        // such bodies per wave, and both halves of the loop have the same shape)
+#ifndef SL_LOOP_LOOSE
         for (;;) {
             SL_USE(j0, p0, v0)
+            if (!__ballot(live)) { SL_USE(j1, p1, v1) break; }
             j0 = pop();
-            if (!__ballot(live)) { SL_USE(j1, p1, v1) SL_FETCH(j0, p0, v0) SL_USE(j0, p0, v0) break; }
+            SL_FETCH(j0, p0, v0)
+            SL_USE(j1, p1, v1)
+            if (!__ballot(live)) { SL_USE(j0, p0, v0) break; }
+            j1 = pop();
+            SL_FETCH(j1, p1, v1)
+        }
+#else
+        while (__ballot(live)) {
+            SL_USE(j0, p0, v0)
+            j0 = pop();
             SL_FETCH(j0, p0, v0)
             SL_USE(j1, p1, v1)
             j1 = pop();
-            if (!__ballot(live)) { SL_USE(j0, p0, v0) SL_FETCH(j1, p1, v1) SL_USE(j1, p1, v1) break; }
             SL_FETCH(j1, p1, v1)
         }
+        SL_USE(j0, p0, v0)
+        SL_USE(j1, p1, v1)
+#endif
         }
 #undef SL_FETCH
 #undef SL_USE
