@@ -67,6 +67,9 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_K2_THREADS
 #define SL_K2_THREADS (SL_SORT_LANES ? 256 : 64)
 #endif
+#ifndef SL_ADJ_WINDOW
+#define SL_ADJ_WINDOW 0 // records of each of the two adjacent-row windows (SL_SORT_LANES only)
+#endif
 #ifndef SL_EXP_LDSONLY
 #define SL_EXP_LDSONLY 0
 #endif
@@ -553,13 +556,56 @@ void k_force_list(DevParams P, SweepArgs A) {
 #if SL_SORT_LANES
     // (one window per workgroup: the records around its SL_K2_THREADS rows)
 #define SL_WG_WINDOW (SL_K2_THREADS + SL_WINDOW - SPH_WAVE)
-    __shared__ float4 win[2 * SL_WG_WINDOW];
+    __shared__ float4 win[2 * (SL_WG_WINDOW + 2 * SL_ADJ_WINDOW)];
 #ifdef SL_PAD_LDS // (perf experiment: fewer resident workgroups per CU, nothing else changed)
     __shared__ float padLds[SL_PAD_LDS / 4];
     if (A.n_all < 0) padLds[threadIdx.x] = 1.f, pi.x = padLds[threadIdx.x ^ 1];
 #endif
     const int w0 = max(R0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WG_WINDOW, A.n_all - w0), 0);
+#if SL_ADJ_WINDOW
+    // Two more windows: the records of the grid rows y - 1 and y + 1 over the x-range of the group's own
+    // cells +- 1 (under the flattened key a contiguous range of the sorted stream; each carries ~12 % of the
+    // hits, the own row ~40 %).  Any choice is correct -- a window holds copies of pv8 records.
+    int adjS[2] = {0, 0}, adjL[2] = {0, 0};
+    {
+        const int rowA = max(R0, rb), rowB = min(R0 + SL_K2_THREADS, re) - 1;
+        if (rowB >= rowA && !P.morton) {
+            const float4 pa = A.pv8[2 * (size_t)rowA], pb = A.pv8[2 * (size_t)rowB];
+            const int3 ca = sweep_cell(P, pa.x, pa.y, pa.z), cb = sweep_cell(P, pb.x, pb.y, pb.z);
+            const int xb = (cb.y == ca.y && cb.z == ca.z) ? cb.x : P.D - 1;
+            const int x0 = max(ca.x - 1, 0), x1 = min(xb + 1, P.D - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int y = ca.y + 2 * t - 1;
+                if (y < 0 || y >= P.D) continue;
+                const int2 *row = A.cellRange + (size_t)y * P.D + (size_t)ca.z * P.D * P.D;
+                // (empty cells hold {0, 0}: the first / last occupied cell among three at either end)
+                const int2 f0 = row[x0], f1 = row[min(x0 + 1, x1)], f2 = row[min(x0 + 2, x1)];
+                const int2 l0 = row[x1], l1 = row[max(x1 - 1, x0)], l2 = row[max(x1 - 2, x0)];
+                const int2 f = f0.y > f0.x ? f0 : (f1.y > f1.x ? f1 : f2);
+                const int2 l = l0.y > l0.x ? l0 : (l1.y > l1.x ? l1 : l2);
+                if (f.y > f.x && l.y > l.x && l.y > f.x) {
+                    adjS[t] = f.x;
+                    adjL[t] = min(l.y - f.x, SL_ADJ_WINDOW);
+                }
+            }
+        }
+        adjS[0] = __builtin_amdgcn_readfirstlane(adjS[0]);
+        adjL[0] = __builtin_amdgcn_readfirstlane(adjL[0]);
+        adjS[1] = __builtin_amdgcn_readfirstlane(adjS[1]);
+        adjL[1] = __builtin_amdgcn_readfirstlane(adjL[1]);
+    }
+#endif
+    // LDS record index of sorted row j, or -1
+    auto locate = [&](int j) -> int {
+        int a = ((unsigned)(j - w0) < (unsigned)wlen) ? j - w0 : -1;
+#if SL_ADJ_WINDOW
+        a = ((unsigned)(j - adjS[0]) < (unsigned)adjL[0]) ? SL_WG_WINDOW + (j - adjS[0]) : a;
+        a = ((unsigned)(j - adjS[1]) < (unsigned)adjL[1]) ? SL_WG_WINDOW + SL_ADJ_WINDOW + (j - adjS[1]) : a;
+#endif
+        return a;
+    };
 #else
     __shared__ float4 winAll[SL_K2_THREADS / SPH_WAVE][2 * SL_WINDOW];
     float4 *win = winAll[threadIdx.x >> 6];
@@ -593,6 +639,12 @@ void k_force_list(DevParams P, SweepArgs A) {
 #if SL_SORT_LANES
         // (the window is staged by the whole workgroup, whatever its waves find in their streams)
         for (int k = threadIdx.x; k < 2 * wlen; k += SL_K2_THREADS) win[k] = A.pv8[2 * (size_t)w0 + k];
+#if SL_ADJ_WINDOW
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            for (int k = threadIdx.x; k < 2 * adjL[t]; k += SL_K2_THREADS)
+                win[2 * (SL_WG_WINDOW + t * SL_ADJ_WINDOW) + k] = A.pv8[2 * (size_t)adjS[t] + k];
+#endif
         __syncthreads();
         const uint4 *const sbase = reinterpret_cast<const uint4 *>(A.maskPool);
         const uint32_t send = valid ? baseq + (uint32_t)Q * SPH_WAVE : 0u;       // per lane: end of its row's quads
@@ -744,17 +796,27 @@ typedef float sl_f4 __attribute__((ext_vector_type(4)));
 #else
 #define SL_UNDEF4(q)
 #endif
+#if SL_SORT_LANES
+#define SL_INWIN(j) (locate(j) >= 0)
+#define SL_WINREC(j) locate(j)
+#else
+#define SL_INWIN(j) ((unsigned)((j)-w0) < (unsigned)wlen)
+#define SL_WINREC(j) ((j)-w0)
+#endif
 #define SL_FETCH(j, p, v)                                                      \
     SL_UNDEF4(p)                                                               \
     SL_UNDEF4(v)                                                               \
-    if ((unsigned)((j)-w0) >= (unsigned)wlen) {                                \
+    if (!SL_INWIN(j)) {                                                        \
         p = SL_GLOAD(A.pv8 + 2 * (size_t)(j));                                 \
         v = SL_GLOAD(A.pv8 + 2 * (size_t)(j) + 1);                             \
     }
 #define SL_USE(j, p, v)                                                        \
-    if ((unsigned)((j)-w0) < (unsigned)wlen) {                                 \
-        p = win[2 * ((j)-w0)];                                                 \
-        v = win[2 * ((j)-w0) + 1];                                             \
+    {                                                                          \
+        const int a_ = SL_WINREC(j);                                           \
+        if (SL_INWIN(j)) {                                                     \
+            p = win[2 * a_];                                                   \
+            v = win[2 * a_ + 1];                                               \
+        }                                                                      \
     }                                                                          \
     body(p, v);
 #else
@@ -771,7 +833,25 @@ typedef float sl_f4 __attribute__((ext_vector_type(4)));
         // (`live` after a pop: some lane has a hit beyond the ones popped so far.  An exhausted lane pops itself:
         // dist = 0, an exact no-op -- so the exit test is made once per two bodies, at the price of at most two
         // such bodies per wave, and both halves of the loop have the same shape)
-#ifndef SL_LOOP_LOOSE
+#if defined(SL_DEPTH3) // (perf experiment: three gathers in flight)
+        float4 p2 = p0, v2 = p0;
+        int j2 = pop();
+        SL_FETCH(j2, p2, v2)
+        for (;;) {
+            SL_USE(j0, p0, v0)
+            if (!__ballot(live)) { SL_USE(j1, p1, v1) SL_USE(j2, p2, v2) break; }
+            j0 = pop();
+            SL_FETCH(j0, p0, v0)
+            SL_USE(j1, p1, v1)
+            if (!__ballot(live)) { SL_USE(j2, p2, v2) SL_USE(j0, p0, v0) break; }
+            j1 = pop();
+            SL_FETCH(j1, p1, v1)
+            SL_USE(j2, p2, v2)
+            if (!__ballot(live)) { SL_USE(j0, p0, v0) SL_USE(j1, p1, v1) break; }
+            j2 = pop();
+            SL_FETCH(j2, p2, v2)
+        }
+#elif !defined(SL_LOOP_LOOSE)
         for (;;) {
             SL_USE(j0, p0, v0)
             if (!__ballot(live)) { SL_USE(j1, p1, v1) break; }
