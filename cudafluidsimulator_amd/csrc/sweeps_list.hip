@@ -67,6 +67,7 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_K2_THREADS
 #define SL_K2_THREADS (SL_SORT_LANES ? 256 : 64)
 #endif
+static_assert(SL_K2_THREADS % SPH_WAVE == 0 && SL_K2_THREADS >= SPH_WAVE && SL_K2_THREADS <= 1024, "force workgroup: whole waves");
 #ifndef SL_ADJ_WINDOW
 #define SL_ADJ_WINDOW 0 // records of each of the two adjacent-row windows (SL_SORT_LANES only)
 #endif
@@ -502,7 +503,7 @@ void k_force_list(DevParams P, SweepArgs A) {
         const int t = threadIdx.x, row = R0 + t;
         const uint32_t cnt = (row >= rb && row < re) ? A.hitCount[row] : 0u;
         const uint32_t bucket = min(cnt >> SL_SORT_SHIFT, 127u);
-        if (t < 128) sortBase[t] = 0u;
+        for (int b = t; b < 128; b += SL_K2_THREADS) sortBase[b] = 0u;
         __syncthreads();
         const uint32_t slot = atomicAdd(&sortBase[bucket], 1u);
         __syncthreads();
