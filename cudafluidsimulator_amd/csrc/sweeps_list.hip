@@ -499,9 +499,31 @@ void k_force_list(DevParams P, SweepArgs A) {
     __shared__ uint32_t sortBase[128];
     __shared__ uint16_t rowOf[SL_K2_THREADS];
     const int R0 = A.i_origin + tileIdx * SL_K2_THREADS;
-    {
+    // A group whose rows are all quiet keeps them in place: the filter leaves such rows the few pairs with
+    // not-quiet neighbours, whatever they recorded, and a wave that reads the streams of its OWN 64 rows reads
+    // whole lines (a dealt wave reads 16 bytes here and there of four waves' quads: n = 16,777,216 -i random,
+    // where free fall is not pressure-free and the sweep is the reading and filtering of the stream:
+    // 3.56 ms unsorted, 4.61 with every group dealt).
+    bool inPlace = false, rowQuiet = false;
+    if (A.quiet) {
+        const int t = threadIdx.x, r0 = R0 + (t & ~63);               // this wave's 64 rows: one word
+        const int lo = max(rb - r0, 0), hi = min(re - r0, 64);           // ... and the valid ones among them
+        const unsigned long long vm = hi > lo ? ((hi - lo == 64 ? ~0ull : (1ull << (hi - lo)) - 1ull) << lo) : 0ull;
+        const unsigned long long qw = reinterpret_cast<const unsigned long long *>(A.quiet)[r0 >> 6];
+        inPlace = __syncthreads_and((qw & vm) == vm) != 0;
+        rowQuiet = (qw >> (t & 63)) & 1ull;
+    }
+    rowOf[threadIdx.x] = (uint16_t)threadIdx.x;
+    if (!inPlace) {
         const int t = threadIdx.x, row = R0 + t;
+        // (a quiet row keeps only its pairs with not-quiet neighbours, few whatever it recorded: bucket 0, with
+        // the rows outside the range -- quiet and busy rows come in patches, and a wave that mixes them runs as
+        // long as its busy rows)
+#ifndef SL_SORT_QUIET_AS_HITS
+        const uint32_t cnt = (row >= rb && row < re && !rowQuiet) ? A.hitCount[row] : 0u;
+#else
         const uint32_t cnt = (row >= rb && row < re) ? A.hitCount[row] : 0u;
+#endif
         const uint32_t bucket = min(cnt >> SL_SORT_SHIFT, 127u);
         for (int b = t; b < 128; b += SL_K2_THREADS) sortBase[b] = 0u;
         __syncthreads();
@@ -523,7 +545,11 @@ void k_force_list(DevParams P, SweepArgs A) {
         rowOf[sortBase[bucket] + slot] = (uint16_t)t;
         __syncthreads();
     }
+#ifdef SL_SORT_IDENTITY // (perf experiment: the workgroup structure without the permutation)
+    const int i = R0 + (int)threadIdx.x;
+#else
     const int i = R0 + (int)rowOf[threadIdx.x];
+#endif
 #else
     const int i = A.i_origin + tileIdx * blockDim.x + threadIdx.x;
 #endif
@@ -638,15 +664,6 @@ void k_force_list(DevParams P, SweepArgs A) {
         // (uniform base + one 32-bit per-lane quad index: a per-lane 64-bit pointer, a quad counter and a
         // per-lane end cost three more VGPRs, and the 73rd costs the seventh resident wave)
 #if SL_SORT_LANES
-        // (the window is staged by the whole workgroup, whatever its waves find in their streams)
-        for (int k = threadIdx.x; k < 2 * wlen; k += SL_K2_THREADS) win[k] = A.pv8[2 * (size_t)w0 + k];
-#if SL_ADJ_WINDOW
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            for (int k = threadIdx.x; k < 2 * adjL[t]; k += SL_K2_THREADS)
-                win[2 * (SL_WG_WINDOW + t * SL_ADJ_WINDOW) + k] = A.pv8[2 * (size_t)adjS[t] + k];
-#endif
-        __syncthreads();
         const uint4 *const sbase = reinterpret_cast<const uint4 *>(A.maskPool);
         const uint32_t send = valid ? baseq + (uint32_t)Q * SPH_WAVE : 0u;       // per lane: end of its row's quads
         uint32_t sidx = valid ? baseq + (uint32_t)(rel & 63) : 0u;               // this lane's next quad
@@ -682,6 +699,19 @@ void k_force_list(DevParams P, SweepArgs A) {
             }
         };
         fetch();
+#if SL_SORT_LANES
+        // the window is staged by the whole workgroup -- unless none of its lanes has anything left after the filter
+        if (__syncthreads_or(mq[0] != 0u)) {
+            for (int k = threadIdx.x; k < 2 * wlen; k += SL_K2_THREADS) win[k] = A.pv8[2 * (size_t)w0 + k];
+#if SL_ADJ_WINDOW
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                for (int k = threadIdx.x; k < 2 * adjL[t]; k += SL_K2_THREADS)
+                    win[2 * (SL_WG_WINDOW + t * SL_ADJ_WINDOW) + k] = A.pv8[2 * (size_t)adjS[t] + k];
+#endif
+            __syncthreads();
+        }
+#endif
         // A wave whose lanes have nothing left after the filter (fluid in free fall) skips the sweep:
         // no window, no gathers, straight to the integration.
         if (__ballot(mq[0] != 0u)) {

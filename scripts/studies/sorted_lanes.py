@@ -23,7 +23,7 @@ u, cnt = np.unique(v, return_counts=True)
 quiet = (v == u[cnt.argmax()]) & (rho <= 1000.0)
 rng = np.random.default_rng(9)
 groups = np.sort(rng.choice(n // (64 * G), size=ng, replace=False))
-tot = dict(bodies=0, trips_now=0, trips_sorted_hits=0, trips_sorted_bodies=0)
+tot = dict(bodies=0, trips_now=0, trips_sorted_hits=0, trips_sorted_bodies=0, g2=0, g4=0, g8=0)
 for g in groups:
     i0 = g * 64 * G
     hits = np.zeros(64 * G, np.int64)
@@ -46,7 +46,11 @@ for g in groups:
     tot["trips_now"] += int(bodies.reshape(G, 64).max(axis=1).sum())
     tot["trips_sorted_hits"] += int(bodies[np.argsort(hits, kind="stable")].reshape(G, 64).max(axis=1).sum())
     tot["trips_sorted_bodies"] += int(np.sort(bodies).reshape(G, 64).max(axis=1).sum())
+    for gs in (2, 4, 8):  # rows dealt in groups of gs ADJACENT rows (sorted by the group's largest hit count)
+        o = np.argsort(hits.reshape(-1, gs).max(axis=1), kind="stable")
+        tot["g%d" % gs] += int(bodies.reshape(-1, gs)[o].reshape(G, 64).max(axis=1).sum())
 ideal = tot["bodies"] / 64
 print(f"{sys.argv[1]}: {ng} groups of {G} waves; lane efficiency (bodies / (64 x trips)): today {ideal/tot['trips_now']:.3f}, rows dealt to lanes "
       f"sorted by recorded hits {ideal/tot['trips_sorted_hits']:.3f}, sorted by pair bodies after the filter {ideal/tot['trips_sorted_bodies']:.3f}; "
+      f"groups of 2 / 4 / 8 adjacent rows {ideal/tot['g2']:.3f} / {ideal/tot['g4']:.3f} / {ideal/tot['g8']:.3f}; "
       f"trips {tot['trips_now']} -> {tot['trips_sorted_hits']} ({100*(1-tot['trips_sorted_hits']/tot['trips_now']):.1f} % fewer)")
