@@ -211,7 +211,7 @@ def roofline_of(n_local, kt, sweep, counts):
             roof["force_zero_pairs_dropped"] = 1.0 - bodies / recorded
             roof["force_valu_frac"] = bodies * FORCE_LANEOPS_PER_PAIR / force_s / VALU_PEAK_LANEOPS
             roof["force_valu_frac_note"] = (
-                f"k_force_list: pair bodies actually evaluated (popcount of the hit masks after the zero-pair "
+                f"k_force_dealt: pair bodies actually evaluated (popcount of the hit masks after the zero-pair "
                 f"filter, counted on the GPU) x {FORCE_LANEOPS_PER_PAIR} lane-ops (SURVEY.md 8d convention) / "
                 f"launch time / VALU peak")
         elif sweep in ("lds", "direct"):

@@ -51,25 +51,8 @@ __device__ __forceinline__ unsigned long long sl_stamp() {
 #ifndef SL_K1_THREADS
 #define SL_K1_THREADS 64
 #endif
-// SL_SORT_LANES: a force workgroup takes SL_K2_THREADS consecutive rows and deals them to its lanes SORTED by the
-// hit counts the density sweep recorded, so that the 64 lanes of a wave run out of hits at about the same
-// time (a wave's trips = its longest lane).  Every lane still walks its own row's stream in canonical order:
-// same results.  Lane efficiency on oracle states (scripts/studies/sorted_lanes.py): 0.79-0.84 -> 0.92-0.93
-// with 4-wave groups (10-14 % fewer trips), 0.965 with 8.
-// Measured (n = 4,194,304 -i random, 100 steps): force sweep 0.812 -> 0.777 ms per step averaged over the run
-// (2.80 -> 2.66 ms at steps 81..100); groups of 128 / 512 rows: 0.792 / 0.805; buckets of 2 / 4 hits: the same.
-#ifndef SL_SORT_LANES
-#define SL_SORT_LANES 1
-#endif
-#ifndef SL_SORT_SHIFT
-#define SL_SORT_SHIFT 3 // 128 buckets of (1 << SL_SORT_SHIFT) hits
-#endif
 #ifndef SL_K2_THREADS
-#define SL_K2_THREADS (SL_SORT_LANES ? 256 : 64)
-#endif
-static_assert(SL_K2_THREADS % SPH_WAVE == 0 && SL_K2_THREADS >= SPH_WAVE && SL_K2_THREADS <= 1024, "force workgroup: whole waves");
-#ifndef SL_ADJ_WINDOW
-#define SL_ADJ_WINDOW 0 // records of each of the two adjacent-row windows (SL_SORT_LANES only)
+#define SL_K2_THREADS 64 // k_force_list (the one-wave-per-workgroup sweep; production is k_force_dealt below)
 #endif
 #ifndef SL_EXP_LDSONLY
 #define SL_EXP_LDSONLY 0
@@ -467,7 +450,8 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-// force + integrate over the recorded hits
+// force + integrate over the recorded hits, one wave per workgroup, rows in place
+// (-DSL_DEAL=0: the A/B partner of k_force_dealt, and the home of the round-2/3 experiments)
 // ---------------------------------------------------------------------------
 // Measured dead end: non-temporal (`nt`) loads of the hit stream and stores of it in the
 // density sweep, meant to keep the stream from pushing neighbour records out of L2:
@@ -493,85 +477,17 @@ void k_force_list(DevParams P, SweepArgs A) {
                         xcd_tile(second ? (int)blockIdx.x - A.nblk1 : (int)blockIdx.x,
                                  second ? (int)gridDim.x - A.nblk1 : A.nblk1,
                                  A.tileChunk * (256 / SL_K2_THREADS), A.tileRotate);
-#if SL_SORT_LANES
-    // the tile's rows, dealt to the lanes in ascending order of their recorded hit counts (counting sort over
-    // 128 buckets of eight: any permutation is correct, a sorted one wastes the fewest trips)
-    __shared__ uint32_t sortBase[128];
-    __shared__ uint16_t rowOf[SL_K2_THREADS];
-    const int R0 = A.i_origin + tileIdx * SL_K2_THREADS;
-    // A group whose rows are all quiet keeps them in place: the filter leaves such rows the few pairs with
-    // not-quiet neighbours, whatever they recorded, and a wave that reads the streams of its OWN 64 rows reads
-    // whole lines (a dealt wave reads 16 bytes here and there of four waves' quads: n = 16,777,216 -i random,
-    // where free fall is not pressure-free and the sweep is the reading and filtering of the stream:
-    // 3.56 ms unsorted, 4.61 with every group dealt).
-    bool inPlace = false, rowQuiet = false;
-    if (A.quiet) {
-        const int t = threadIdx.x, r0 = R0 + (t & ~63);               // this wave's 64 rows: one word
-        const int lo = max(rb - r0, 0), hi = min(re - r0, 64);           // ... and the valid ones among them
-        const unsigned long long vm = hi > lo ? ((hi - lo == 64 ? ~0ull : (1ull << (hi - lo)) - 1ull) << lo) : 0ull;
-        const unsigned long long qw = reinterpret_cast<const unsigned long long *>(A.quiet)[r0 >> 6];
-        inPlace = __syncthreads_and((qw & vm) == vm) != 0;
-        rowQuiet = (qw >> (t & 63)) & 1ull;
-    }
-    rowOf[threadIdx.x] = (uint16_t)threadIdx.x;
-    if (!inPlace) {
-        const int t = threadIdx.x, row = R0 + t;
-        // (a quiet row keeps only its pairs with not-quiet neighbours, few whatever it recorded: bucket 0, with
-        // the rows outside the range -- quiet and busy rows come in patches, and a wave that mixes them runs as
-        // long as its busy rows)
-#ifndef SL_SORT_QUIET_AS_HITS
-        const uint32_t cnt = (row >= rb && row < re && !rowQuiet) ? A.hitCount[row] : 0u;
-#else
-        const uint32_t cnt = (row >= rb && row < re) ? A.hitCount[row] : 0u;
-#endif
-        const uint32_t bucket = min(cnt >> SL_SORT_SHIFT, 127u);
-        for (int b = t; b < 128; b += SL_K2_THREADS) sortBase[b] = 0u;
-        __syncthreads();
-        const uint32_t slot = atomicAdd(&sortBase[bucket], 1u);
-        __syncthreads();
-        if (t < SPH_WAVE) { // exclusive scan of the bucket counts, two per lane of the first wave
-            const uint32_t a = sortBase[2 * t], b = sortBase[2 * t + 1];
-            uint32_t incl = a + b;
-#pragma unroll
-            for (int off = 1; off < SPH_WAVE; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off);
-                incl += t >= off ? up : 0u;
-            }
-            const uint32_t excl = incl - (a + b);
-            sortBase[2 * t] = excl;
-            sortBase[2 * t + 1] = excl + a;
-        }
-        __syncthreads();
-        rowOf[sortBase[bucket] + slot] = (uint16_t)t;
-        __syncthreads();
-    }
-#ifdef SL_SORT_IDENTITY // (perf experiment: the workgroup structure without the permutation)
-    const int i = R0 + (int)threadIdx.x;
-#else
-    const int i = R0 + (int)rowOf[threadIdx.x];
-#endif
-#else
     const int i = A.i_origin + tileIdx * blockDim.x + threadIdx.x;
-#endif
-    const bool inRange = i >= rb && i < re;
-    const int iSafe = inRange ? i : rb;
+    const bool valid = i >= rb && i < re;
+    const int iSafe = valid ? i : rb;
     float4 pi = A.pv8[2 * (size_t)iSafe];
     const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
     const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
-    // the row's hit stream (layout: k_density_mask_lds): wave w of the density sweep owns rows [i_origin + 64 w,
-    // +64) and Q quads per lane; quad q of its lane l at (base + 64 q + l) = two (first candidate, mask) pairs
-#if SL_SORT_LANES
-    const int rel = iSafe - A.i_origin;
-    const uint32_t baseq = inRange ? A.maskOff[2 * (size_t)(rel >> 6)] : SL_NONE; // per lane: rows of several waves
-    const int Q = inRange ? (int)A.maskOff[2 * (size_t)(rel >> 6) + 1] : 0;
-    // (a row whose density wave found the pool exhausted has no stream: k_force_fallback integrates it)
-    const bool valid = inRange && baseq != SL_NONE;
-#else
-    const bool valid = inRange;
+    // this wave's hit stream (layout: k_density_mask_lds): Q quads per lane, quad q of
+    // this lane at stream4[q * 64] = two (first candidate, 32-bit hit mask) pairs
     const int wv = tileIdx * (SL_K2_THREADS / SPH_WAVE) + (threadIdx.x >> 6);
     const uint32_t baseq = __builtin_amdgcn_readfirstlane(A.maskOff[2 * (size_t)wv]);
     const int Q = __builtin_amdgcn_readfirstlane((int)A.maskOff[2 * (size_t)wv + 1]);
-#endif
     ForceAcc F = {0.f, 0.f, 0.f};
 
 #if SL_WINDOW
@@ -580,60 +496,6 @@ void k_force_list(DevParams P, SweepArgs A) {
     // hits are neighbours in the particle's own grid row, i.e. within a few dozen
     // slots of the wave's 64 particles in the sorted stream: those are served by
     // ds_read_b128 instead of a 64-address global gather.
-#if SL_SORT_LANES
-    // (one window per workgroup: the records around its SL_K2_THREADS rows)
-#define SL_WG_WINDOW (SL_K2_THREADS + SL_WINDOW - SPH_WAVE)
-    __shared__ float4 win[2 * (SL_WG_WINDOW + 2 * SL_ADJ_WINDOW)];
-#ifdef SL_PAD_LDS // (perf experiment: fewer resident workgroups per CU, nothing else changed)
-    __shared__ float padLds[SL_PAD_LDS / 4];
-    if (A.n_all < 0) padLds[threadIdx.x] = 1.f, pi.x = padLds[threadIdx.x ^ 1];
-#endif
-    const int w0 = max(R0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
-    const int wlen = max(min(SL_WG_WINDOW, A.n_all - w0), 0);
-#if SL_ADJ_WINDOW
-    // Two more windows: the records of the grid rows y - 1 and y + 1 over the x-range of the group's own
-    // cells +- 1 (under the flattened key a contiguous range of the sorted stream; each carries ~12 % of the
-    // hits, the own row ~40 %).  Any choice is correct -- a window holds copies of pv8 records.
-    int adjS[2] = {0, 0}, adjL[2] = {0, 0};
-    {
-        const int rowA = max(R0, rb), rowB = min(R0 + SL_K2_THREADS, re) - 1;
-        if (rowB >= rowA && !P.morton) {
-            const float4 pa = A.pv8[2 * (size_t)rowA], pb = A.pv8[2 * (size_t)rowB];
-            const int3 ca = sweep_cell(P, pa.x, pa.y, pa.z), cb = sweep_cell(P, pb.x, pb.y, pb.z);
-            const int xb = (cb.y == ca.y && cb.z == ca.z) ? cb.x : P.D - 1;
-            const int x0 = max(ca.x - 1, 0), x1 = min(xb + 1, P.D - 1);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int y = ca.y + 2 * t - 1;
-                if (y < 0 || y >= P.D) continue;
-                const int2 *row = A.cellRange + (size_t)y * P.D + (size_t)ca.z * P.D * P.D;
-                // (empty cells hold {0, 0}: the first / last occupied cell among three at either end)
-                const int2 f0 = row[x0], f1 = row[min(x0 + 1, x1)], f2 = row[min(x0 + 2, x1)];
-                const int2 l0 = row[x1], l1 = row[max(x1 - 1, x0)], l2 = row[max(x1 - 2, x0)];
-                const int2 f = f0.y > f0.x ? f0 : (f1.y > f1.x ? f1 : f2);
-                const int2 l = l0.y > l0.x ? l0 : (l1.y > l1.x ? l1 : l2);
-                if (f.y > f.x && l.y > l.x && l.y > f.x) {
-                    adjS[t] = f.x;
-                    adjL[t] = min(l.y - f.x, SL_ADJ_WINDOW);
-                }
-            }
-        }
-        adjS[0] = __builtin_amdgcn_readfirstlane(adjS[0]);
-        adjL[0] = __builtin_amdgcn_readfirstlane(adjL[0]);
-        adjS[1] = __builtin_amdgcn_readfirstlane(adjS[1]);
-        adjL[1] = __builtin_amdgcn_readfirstlane(adjL[1]);
-    }
-#endif
-    // LDS record index of sorted row j, or -1
-    auto locate = [&](int j) -> int {
-        int a = ((unsigned)(j - w0) < (unsigned)wlen) ? j - w0 : -1;
-#if SL_ADJ_WINDOW
-        a = ((unsigned)(j - adjS[0]) < (unsigned)adjL[0]) ? SL_WG_WINDOW + (j - adjS[0]) : a;
-        a = ((unsigned)(j - adjS[1]) < (unsigned)adjL[1]) ? SL_WG_WINDOW + SL_ADJ_WINDOW + (j - adjS[1]) : a;
-#endif
-        return a;
-    };
-#else
     __shared__ float4 winAll[SL_K2_THREADS / SPH_WAVE][2 * SL_WINDOW];
     float4 *win = winAll[threadIdx.x >> 6];
 #if SL_LDSDMA
@@ -644,14 +506,11 @@ void k_force_list(DevParams P, SweepArgs A) {
     const int w0 = max(tile0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     const int wlen = max(min(SL_WINDOW, A.n_all - w0), 0);
 #endif
-#endif
 
     // A wave that found the mask pool exhausted has no stream: its particles are
     // handled by k_force_fallback (kept out of this kernel: its 27 table reads and
     // run arrays would cost two resident waves per SIMD here).
-#if !SL_SORT_LANES
     if (baseq == SL_NONE) return;
-#endif
     // Every row of the domain quiet (fluid in free fall): no pair adds anything -- the hit stream is
     // not even read, the sweep is the integration alone.
     const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u;
@@ -663,15 +522,9 @@ void k_force_list(DevParams P, SweepArgs A) {
         // every term: exact no-op).
         // (uniform base + one 32-bit per-lane quad index: a per-lane 64-bit pointer, a quad counter and a
         // per-lane end cost three more VGPRs, and the 73rd costs the seventh resident wave)
-#if SL_SORT_LANES
-        const uint4 *const sbase = reinterpret_cast<const uint4 *>(A.maskPool);
-        const uint32_t send = valid ? baseq + (uint32_t)Q * SPH_WAVE : 0u;       // per lane: end of its row's quads
-        uint32_t sidx = valid ? baseq + (uint32_t)(rel & 63) : 0u;               // this lane's next quad
-#else
         const uint4 *const sbase = reinterpret_cast<const uint4 *>(A.maskPool) + baseq;
         const uint32_t send = (uint32_t)Q * SPH_WAVE;                           // uniform: end of the wave's quads
         uint32_t sidx = valid ? (threadIdx.x & 63u) : send;                      // this lane's next quad
-#endif
         uint32_t m = 0, mq[2] = {0u, 0u};
         int jb = 0, jq[2] = {0, 0};
         bool live = true;
@@ -699,23 +552,10 @@ void k_force_list(DevParams P, SweepArgs A) {
             }
         };
         fetch();
-#if SL_SORT_LANES
-        // the window is staged by the whole workgroup -- unless none of its lanes has anything left after the filter
-        if (__syncthreads_or(mq[0] != 0u)) {
-            for (int k = threadIdx.x; k < 2 * wlen; k += SL_K2_THREADS) win[k] = A.pv8[2 * (size_t)w0 + k];
-#if SL_ADJ_WINDOW
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                for (int k = threadIdx.x; k < 2 * adjL[t]; k += SL_K2_THREADS)
-                    win[2 * (SL_WG_WINDOW + t * SL_ADJ_WINDOW) + k] = A.pv8[2 * (size_t)adjS[t] + k];
-#endif
-            __syncthreads();
-        }
-#endif
         // A wave whose lanes have nothing left after the filter (fluid in free fall) skips the sweep:
         // no window, no gathers, straight to the integration.
         if (__ballot(mq[0] != 0u)) {
-#if SL_WINDOW && !SL_SORT_LANES
+#if SL_WINDOW
         {
             const int lane = threadIdx.x & 63;
             for (int k = lane; k < 2 * wlen; k += SPH_WAVE) win[k] = A.pv8[2 * (size_t)w0 + k];
@@ -813,41 +653,15 @@ void k_force_list(DevParams P, SweepArgs A) {
         // fetch: issue the global gather only for lanes whose hit is outside the
         // window (fewer active lanes = fewer addresses for the TA); the LDS copy is
         // read when the hit is consumed.
-        // (a lane's record comes EITHER from the gather or from the window: the registers are declared
-        // undefined before the gather, or the compiler keeps "the old value where no load was issued" alive
-        // through both conditionals -- 14 v_mov per pair body and a second set of record registers)
-#if defined(SL_GATHER_NT) // (perf experiment: cache policy of the gathers)
-typedef float sl_f4 __attribute__((ext_vector_type(4)));
-#define SL_GLOAD(ptr) ([&]() { const sl_f4 t_ = __builtin_nontemporal_load(reinterpret_cast<const sl_f4 *>(ptr)); return make_float4(t_.x, t_.y, t_.z, t_.w); }())
-#else
-#define SL_GLOAD(ptr) (*(ptr))
-#endif
-#ifndef SL_NO_UNDEF
-#define SL_UNDEF4(q) asm volatile("" : "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w));
-#else
-#define SL_UNDEF4(q)
-#endif
-#if SL_SORT_LANES
-#define SL_INWIN(j) (locate(j) >= 0)
-#define SL_WINREC(j) locate(j)
-#else
-#define SL_INWIN(j) ((unsigned)((j)-w0) < (unsigned)wlen)
-#define SL_WINREC(j) ((j)-w0)
-#endif
 #define SL_FETCH(j, p, v)                                                      \
-    SL_UNDEF4(p)                                                               \
-    SL_UNDEF4(v)                                                               \
-    if (!SL_INWIN(j)) {                                                        \
-        p = SL_GLOAD(A.pv8 + 2 * (size_t)(j));                                 \
-        v = SL_GLOAD(A.pv8 + 2 * (size_t)(j) + 1);                             \
+    if ((unsigned)((j)-w0) >= (unsigned)wlen) {                                \
+        p = A.pv8[2 * (size_t)(j)];                                            \
+        v = A.pv8[2 * (size_t)(j) + 1];                                        \
     }
 #define SL_USE(j, p, v)                                                        \
-    {                                                                          \
-        const int a_ = SL_WINREC(j);                                           \
-        if (SL_INWIN(j)) {                                                     \
-            p = win[2 * a_];                                                   \
-            v = win[2 * a_ + 1];                                               \
-        }                                                                      \
+    if ((unsigned)((j)-w0) < (unsigned)wlen) {                                 \
+        p = win[2 * ((j)-w0)];                                                 \
+        v = win[2 * ((j)-w0) + 1];                                             \
     }                                                                          \
     body(p, v);
 #else
@@ -861,50 +675,16 @@ typedef float sl_f4 __attribute__((ext_vector_type(4)));
         SL_FETCH(j0, p0, v0)
         int j1 = pop();
         SL_FETCH(j1, p1, v1)
-        // (`live` after a pop: some lane has a hit beyond the ones popped so far.  An exhausted lane pops itself:
-        // dist = 0, an exact no-op -- so the exit test is made once per two bodies, at the price of at most two
-        // such bodies per wave, and both halves of the loop have the same shape)
-#if defined(SL_DEPTH3) // (perf experiment: three gathers in flight)
-        float4 p2 = p0, v2 = p0;
-        int j2 = pop();
-        SL_FETCH(j2, p2, v2)
         for (;;) {
             SL_USE(j0, p0, v0)
-            if (!__ballot(live)) { SL_USE(j1, p1, v1) SL_USE(j2, p2, v2) break; }
             j0 = pop();
-            SL_FETCH(j0, p0, v0)
-            SL_USE(j1, p1, v1)
-            if (!__ballot(live)) { SL_USE(j2, p2, v2) SL_USE(j0, p0, v0) break; }
-            j1 = pop();
-            SL_FETCH(j1, p1, v1)
-            SL_USE(j2, p2, v2)
-            if (!__ballot(live)) { SL_USE(j0, p0, v0) SL_USE(j1, p1, v1) break; }
-            j2 = pop();
-            SL_FETCH(j2, p2, v2)
-        }
-#elif !defined(SL_LOOP_LOOSE)
-        for (;;) {
-            SL_USE(j0, p0, v0)
-            if (!__ballot(live)) { SL_USE(j1, p1, v1) break; }
-            j0 = pop();
-            SL_FETCH(j0, p0, v0)
-            SL_USE(j1, p1, v1)
-            if (!__ballot(live)) { SL_USE(j0, p0, v0) break; }
-            j1 = pop();
-            SL_FETCH(j1, p1, v1)
-        }
-#else
-        while (__ballot(live)) {
-            SL_USE(j0, p0, v0)
-            j0 = pop();
+            if (!__ballot(live)) { SL_USE(j1, p1, v1) SL_FETCH(j0, p0, v0) SL_USE(j0, p0, v0) break; }
             SL_FETCH(j0, p0, v0)
             SL_USE(j1, p1, v1)
             j1 = pop();
+            if (!__ballot(live)) { SL_USE(j0, p0, v0) SL_FETCH(j1, p1, v1) SL_USE(j1, p1, v1) break; }
             SL_FETCH(j1, p1, v1)
         }
-        SL_USE(j0, p0, v0)
-        SL_USE(j1, p1, v1)
-#endif
         }
 #undef SL_FETCH
 #undef SL_USE
@@ -915,6 +695,233 @@ typedef float sl_f4 __attribute__((ext_vector_type(4)));
         float vx = vi.x, vy = vi.y, vz = vi.z;
         integrate_particle(P, pi, vx, vy, vz, F, vi.w);
         store_particle(A, i, pi, vx, vy, vz, vi.w, F);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// force + integrate over the recorded hits, rows DEALT to lanes (production)
+// ---------------------------------------------------------------------------
+// A wave's trips are its longest lane's hit count; among 64 consecutive rows the counts differ by a
+// factor of two (floor pile next to falling cloud, cell to cell).  A workgroup of four waves therefore
+// takes SL_DEAL_ROWS consecutive rows and deals them to lanes SORTED by the hit counts the density sweep
+// recorded (hitCount[], 4 B per row; an LDS counting sort over 128 buckets), so that the 64 lanes of a
+// wave run out of hits together.  Every lane still walks its OWN row's stream in canonical order
+// (per-lane stream base and end): same bits.  Lane efficiency on oracle states
+// (scripts/studies/sorted_lanes.py): 0.75-0.83 -> 0.89-0.93, 10-17 % fewer trips.
+//  * Quiet rows (zero-pair filter) sort first whatever they recorded: the filter leaves them only their
+//    pairs with not-quiet neighbours, and quiet / busy rows come in patches -- a wave that mixes them runs
+//    as long as its busy rows (n = 16,777,216: 4.61 -> 3.89 ms).  A group whose rows are ALL quiet is not
+//    dealt at all: a wave that reads the streams of its own 64 rows reads whole lines.
+//  * Measured and not kept: groups of 128 / 512 rows (0.792 / 0.805 vs 0.777); 512-row groups whose wave w
+//    sweeps sorted virtual waves w and 7 - w one after the other, a light and a heavy one, so that the four
+//    waves end together (0.92); buckets of 2 .. 64 hits (the same).
+//  * One LDS window per workgroup: the records of its own rows +- 48 (own grid row: ~40 % of all hits),
+//    staged only if one of those rows is not quiet.
+// Measured, n = 4,194,304 -i random, 100 steps: force sweep 0.812 (one wave per workgroup, rows in place)
+// -> 0.777 ms per step with 256-row groups (profiles/r03_experiments.md has every A/B).
+#ifndef SL_DEAL
+#define SL_DEAL 1
+#endif
+#ifndef SL_SORT_SHIFT
+#define SL_SORT_SHIFT 3 // 128 buckets of (1 << SL_SORT_SHIFT) hits (1 .. 6 measured the same)
+#endif
+#define SL_DEAL_THREADS 256
+#define SL_DEAL_ROWS SL_DEAL_THREADS
+#define SL_DEAL_WINDOW (SL_DEAL_ROWS + SL_WINDOW - SPH_WAVE)
+static_assert(SL_WINDOW >= SPH_WAVE, "the dealt sweep needs the window");
+
+template <bool FAST, bool SLIM>
+__global__ __launch_bounds__(SL_DEAL_THREADS) void k_force_dealt(DevParams P, SweepArgs A) {
+    __shared__ uint32_t sortBase[128];
+    __shared__ uint16_t rowOf[SL_DEAL_ROWS];
+    __shared__ float4 win[2 * SL_DEAL_WINDOW];
+    const int t = threadIdx.x, lane = t & 63;
+    // this launch covers the groups that hold rows of [i_begin, i_end) and, past block nblk1, of [i_begin2,
+    // i_end2) (the slab driver runs the interior while the halo densities are still in flight); groups are
+    // numbered from i_origin like the density sweep's waves
+    const bool second = (int)blockIdx.x >= A.nblk1;
+    const int rb = second ? A.i_begin2 : A.i_begin, re = second ? A.i_end2 : A.i_end;
+    const int chunk = A.tileChunk > 0 ? max(A.tileChunk * 256 / SL_DEAL_ROWS, 1) : 0;
+    const int group = ((rb - A.i_origin) >> 6) / (SL_DEAL_ROWS / SPH_WAVE) +
+                      xcd_tile(second ? (int)blockIdx.x - A.nblk1 : (int)blockIdx.x,
+                               second ? (int)gridDim.x - A.nblk1 : A.nblk1, chunk, A.tileRotate);
+    const int R0 = A.i_origin + group * SL_DEAL_ROWS;
+    const unsigned long long *const quiet64 = reinterpret_cast<const unsigned long long *>(A.quiet);
+
+    // ---- the deal ----
+    unsigned long long qw = 0ull; // quiet bits of this wave's 64 rows in place
+    bool inPlace = false;
+    if (A.quiet) {
+        const int r0 = R0 + (t & ~63);
+        const int lo = max(rb - r0, 0), hi = min(re - r0, 64); // the rows of this launch among them
+        const unsigned long long vm = hi > lo ? ((hi - lo == 64 ? ~0ull : (1ull << (hi - lo)) - 1ull) << lo) : 0ull;
+        if (vm) qw = quiet64[r0 >> 6];
+        inPlace = __syncthreads_and((qw & vm) == vm) != 0;
+    }
+    if (!inPlace) {
+        for (int b = t; b < 128; b += SL_DEAL_THREADS) sortBase[b] = 0u;
+        __syncthreads();
+        const int row = R0 + t;
+        const bool counted = row >= rb && row < re && !((qw >> lane) & 1ull);
+        const uint32_t bucket = min((counted ? A.hitCount[row] : 0u) >> SL_SORT_SHIFT, 127u);
+        const uint32_t slot = atomicAdd(&sortBase[bucket], 1u);
+        __syncthreads();
+        if (t < SPH_WAVE) { // exclusive scan of the bucket counts, two per lane of the first wave
+            const uint32_t a = sortBase[2 * t], b = sortBase[2 * t + 1];
+            uint32_t incl = a + b;
+#pragma unroll
+            for (int off = 1; off < SPH_WAVE; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                incl += t >= off ? up : 0u;
+            }
+            const uint32_t excl = incl - (a + b);
+            sortBase[2 * t] = excl;
+            sortBase[2 * t + 1] = excl + a;
+        }
+        __syncthreads();
+        rowOf[sortBase[bucket] + slot] = (uint16_t)t;
+    }
+
+    // ---- the window ----
+    // Every row of the domain quiet (fluid in free fall): no pair adds anything -- the hit stream is not even
+    // read, the sweep is the integration alone.
+    const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u;
+    const int w0 = max(R0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
+    int wlen = max(min(SL_DEAL_WINDOW, A.n_all - w0), 0);
+    {
+        // a quiet row's pairs with quiet rows are dropped: a window of quiet rows serves nobody
+        bool wanted = !allQuiet && wlen > 0;
+        if (wanted && A.quiet) {
+            const int k0 = w0 >> 6, k1 = (w0 + wlen - 1) >> 6; // (whole words: some rows beyond either end count too)
+            wanted = k0 + t <= k1 && quiet64[k0 + t] != ~0ull;
+        }
+        if (__syncthreads_or(wanted)) { // (also orders the deal's rowOf[] writes before their reads)
+            for (int k = t; k < 2 * wlen; k += SL_DEAL_THREADS) win[k] = A.pv8[2 * (size_t)w0 + k];
+            __syncthreads();
+        } else {
+            wlen = 0;
+        }
+    }
+
+    // ---- the sweep of this lane's row ----
+    {
+        const int i = R0 + (inPlace ? t : (int)rowOf[t]);
+        const bool inRange = i >= rb && i < re;
+        const int iSafe = inRange ? i : rb;
+        float4 pi = A.pv8[2 * (size_t)iSafe];
+        const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
+        const float prs_i = fmaxf(0.f, SPH_GAS_CONSTANT * (vi.w - SPH_REST_DENSITY));
+        // the row's hit stream (layout: k_density_mask_lds): wave v of the density sweep owns rows [i_origin + 64 v,
+        // +64) and Q quads per lane; quad q of its lane l at (base + 64 q + l) = two (first candidate, mask) pairs
+        const int rel = iSafe - A.i_origin;
+        const uint32_t baseq = inRange ? A.maskOff[2 * (size_t)(rel >> 6)] : SL_NONE;
+        const int Q = inRange ? (int)A.maskOff[2 * (size_t)(rel >> 6) + 1] : 0;
+        // (a row whose density wave found the pool exhausted has no stream: k_force_fallback integrates it)
+        const bool valid = inRange && baseq != SL_NONE;
+        ForceAcc F = {0.f, 0.f, 0.f};
+        if (!allQuiet) {
+            // Bit cursor.  (jb, m): first candidate and remaining bits of the current pair; (jq, mq): the pairs of
+            // the last quad loaded.  A lane's sequence ends with a zero mask (or after Q quads).  pop() returns the
+            // next hit's sorted index, or the particle itself once the stream is exhausted (dist = 0 gates every
+            // term: exact no-op).
+            const uint4 *const sbase = reinterpret_cast<const uint4 *>(A.maskPool);
+            const uint32_t send = valid ? baseq + (uint32_t)Q * SPH_WAVE : 0u; // end of the row's quads
+            uint32_t sidx = valid ? baseq + (uint32_t)(rel & 63) : 0u;         // this lane's next quad
+            uint32_t m = 0, mq[2] = {0u, 0u};
+            int jb = 0, jq[2] = {0, 0};
+            bool live = true;
+            // zero-pair filter: a quiet row drops its quiet candidates
+            const bool qi = A.quiet && valid && ((A.quiet[i >> 5] >> (i & 31)) & 1u);
+            // post-condition: mq[0] != 0, or the lane's sequence is exhausted
+            auto fetch = [&]() {
+                while (sidx < send) {
+                    uint4 q = sbase[sidx];
+                    sidx = (q.w == 0u) ? send : sidx + SPH_WAVE; // a zero mask ends the sequence
+                    if (qi) {
+                        q.y &= ~sl_quiet_window(A.quiet, q.x);
+                        q.w &= ~sl_quiet_window(A.quiet, q.z);
+                    }
+                    if (q.y == 0u) { // first pair empty (filtered, or the terminator): the second moves up
+                        q.x = q.z;
+                        q.y = q.w;
+                        q.w = 0u;
+                    }
+                    jq[0] = (int)q.x;
+                    mq[0] = q.y;
+                    jq[1] = (int)q.z;
+                    mq[1] = q.w;
+                    if (q.y != 0u) break;
+                }
+            };
+            fetch();
+            // A wave whose lanes have nothing left after the filter skips the sweep: no gathers, straight to
+            // the integration.
+            if (__ballot(mq[0] != 0u)) {
+                auto pop = [&]() -> int {
+                    if (m == 0) { // next pair; queued masks are never 0, so mq[0] == 0 means "queue empty"
+                        m = mq[0];
+                        jb = jq[0];
+                        mq[0] = mq[1];
+                        jq[0] = jq[1];
+                        mq[1] = 0;
+                        if (mq[0] == 0) fetch();
+                    }
+                    live = (m | mq[0]) != 0;
+                    const bool has = m != 0;
+                    const int b = has ? __builtin_ctz(m) : 0;
+                    m &= m - 1u; // (0 stays 0)
+                    return has ? jb + b : iSafe;
+                };
+                auto body = [&](const float4 &pj, const float4 &vj) {
+                    if (FAST) force_pair_fast(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
+                    else force_pair<SLIM>(P, pi.x, pi.y, pi.z, vi.x, vi.y, vi.z, prs_i, pj, vj, F);
+                };
+                // Two gathers are always in flight while a pair body is evaluated; the loop is unrolled by two so
+                // the pipeline registers never move.  A record comes EITHER from the gather (issued only by the
+                // lanes whose hit is outside the window: fewer addresses for the texture path) or from the window
+                // (read when the hit is consumed): the registers are declared undefined before the gather, or the
+                // compiler keeps "the old value where no load was issued" alive through both conditionals -- 14
+                // v_mov per pair body and a second set of record registers (70 -> 57 VGPRs).
+#define SD_UNDEF4(q) asm volatile("" : "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w));
+#define SD_FETCH(j, p, v)                                                      \
+    SD_UNDEF4(p)                                                               \
+    SD_UNDEF4(v)                                                               \
+    if ((unsigned)((j)-w0) >= (unsigned)wlen) {                                \
+        p = A.pv8[2 * (size_t)(j)];                                            \
+        v = A.pv8[2 * (size_t)(j) + 1];                                        \
+    }
+#define SD_USE(j, p, v)                                                        \
+    if ((unsigned)((j)-w0) < (unsigned)wlen) {                                 \
+        p = win[2 * ((j)-w0)];                                                 \
+        v = win[2 * ((j)-w0) + 1];                                             \
+    }                                                                          \
+    body(p, v);
+                float4 p0 = make_float4(0, 0, 0, 0), v0 = p0, p1 = p0, v1 = p0;
+                int j0 = pop();
+                SD_FETCH(j0, p0, v0)
+                int j1 = pop();
+                SD_FETCH(j1, p1, v1)
+                // (`live` after a pop: some lane has a hit beyond the ones popped so far)
+                for (;;) {
+                    SD_USE(j0, p0, v0)
+                    if (!__ballot(live)) { SD_USE(j1, p1, v1) break; }
+                    j0 = pop();
+                    SD_FETCH(j0, p0, v0)
+                    SD_USE(j1, p1, v1)
+                    if (!__ballot(live)) { SD_USE(j0, p0, v0) break; }
+                    j1 = pop();
+                    SD_FETCH(j1, p1, v1)
+                }
+#undef SD_FETCH
+#undef SD_USE
+#undef SD_UNDEF4
+            }
+        }
+        if (valid) {
+            float vx = vi.x, vy = vi.y, vz = vi.z;
+            integrate_particle(P, pi, vx, vy, vz, F, vi.w);
+            store_particle(A, i, pi, vx, vy, vz, vi.w, F);
+        }
     }
 }
 
@@ -1021,8 +1028,14 @@ void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode,
     }
     if (B.i_end <= B.i_begin) return;
     if (B.patchHalo) sph_launch_patch_halo(B, s);
-    // waves of the stream (numbered from i_origin) that hold rows of a range
-    const int wpb = SL_K2_THREADS / SPH_WAVE;
+    // groups of the stream's waves (numbered from i_origin) that hold rows of a range
+#if SL_DEAL
+    const int wpb = SL_DEAL_ROWS / SPH_WAVE, threads = SL_DEAL_THREADS;
+#define SL_FORCE_KERNEL k_force_dealt
+#else
+    const int wpb = SL_K2_THREADS / SPH_WAVE, threads = SL_K2_THREADS;
+#define SL_FORCE_KERNEL k_force_list
+#endif
     auto blocks_of = [&](int a, int b) {
         if (b <= a) return 0;
         const int w0 = (a - B.i_origin) >> 6, w1 = (b - B.i_origin + 63) >> 6;
@@ -1033,13 +1046,14 @@ void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode,
     const int hullEnd = B.i_end2 > B.i_begin2 ? B.i_end2 : B.i_end;
     const int blocks = (hullEnd - B.i_begin + SW_THREADS - 1) / SW_THREADS;
     if (mathMode == 1) {
-        k_force_list<true, true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        SL_FORCE_KERNEL<true, true><<<fblocks, threads, 0, s>>>(P, B);
         k_force_fallback<true, true><<<blocks, SW_THREADS, 0, s>>>(P, B);
     } else if (P.slimDiv) { // the reference's h and kernel coefficients (sweep_common.h)
-        k_force_list<false, true><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        SL_FORCE_KERNEL<false, true><<<fblocks, threads, 0, s>>>(P, B);
         k_force_fallback<false, true><<<blocks, SW_THREADS, 0, s>>>(P, B);
     } else {
-        k_force_list<false, false><<<fblocks, SL_K2_THREADS, 0, s>>>(P, B);
+        SL_FORCE_KERNEL<false, false><<<fblocks, threads, 0, s>>>(P, B);
         k_force_fallback<false, false><<<blocks, SW_THREADS, 0, s>>>(P, B);
     }
+#undef SL_FORCE_KERNEL
 }

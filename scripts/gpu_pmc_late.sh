@@ -16,5 +16,5 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
   echo "pass $i ($ctrs) exit $?"
 done
 cd $GRAFT_REPO_ROOT
-python3 scripts/pmc_summary.py $OUT $LAST > $OUT/pmc_summary.csv; grep -E "density_mask|force_list" $OUT/pmc_summary.csv
+python3 scripts/pmc_summary.py $OUT $LAST > $OUT/pmc_summary.csv; grep -E "density_mask|k_force_" $OUT/pmc_summary.csv
 find $OUT -name "*counter_collection.csv" -size +4M -delete

@@ -16,5 +16,5 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INS
   echo "$V pass $i exit $?"
 done
 cd $GRAFT_REPO_ROOT
-python3 scripts/pmc_summary.py $OUT $STEPS > $OUT/pmc_summary.csv; grep -E "force_list" $OUT/pmc_summary.csv | cut -d, -f2- 
+python3 scripts/pmc_summary.py $OUT $STEPS > $OUT/pmc_summary.csv; grep -E "k_force_" $OUT/pmc_summary.csv | cut -d, -f2- 
 find $OUT -name "*counter_collection.csv" -size +4M -delete

@@ -46,7 +46,7 @@ print("value %.3e ms/step %.3f | density %.3f force %.3f sort %.3f gather %.3f h
 print({x: r.get(x) for x in ("frac", "valu_frac", "force_valu_frac", "force_hit_fraction", "traffic")})
 print(d.get("cpu_baseline", {}).get("sample"))
 for row in csv.DictReader(open("$OUT/pmc_summary.csv")):
-    if "density_mask" in row["kernel"] or "force_list" in row["kernel"]:
+    if "density_mask" in row["kernel"] or "k_force_" in row["kernel"]:
         print(row["kernel"][:40], row["counter"], row["avg_per_dispatch"], row["dispatches"], "timed steps only:", row.get("avg_last_%d_dispatches" % $K))
 PY
 head -8 $OUT/prof/bench_kernel_stats.csv | cut -c1-160
