@@ -376,6 +376,11 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
                 // (union vs own range) cost what the gathers cost: density 0.786 -> 0.884 ms over
                 // the 100 steps, 1.72 -> 1.69 at steps 81..100.  A larger slice helps instead:
                 // SW_CAP 256 / 384 / 512 / 640 / 1024: 0.786 / 0.718 / 0.750 / 0.827 / 1.128.)
+                // (measured, round 3: a select-free form of the trips in which no lane is in its LAST, partial
+                // trip -- 60 % of the trips at step 1, 92 % at step 100; one pointer select per lane instead of a
+                // compare and a select per candidate, 6 of 73 VALU instructions -- is bit-identical and SLOWER:
+                // density 0.753 vs 0.70 ms over the 100 steps; the extra ballot and branch per trip cost more
+                // than the selects)
                 if (R.staged) {
                     for (; __ballot(k < len); k += SW_UNROLL) {
                         float4 pj[SW_UNROLL];
