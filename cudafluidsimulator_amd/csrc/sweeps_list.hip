@@ -888,6 +888,13 @@ __global__ __launch_bounds__(SL_DEAL_THREADS) void k_force_dealt(DevParams P, Sw
                 // compiler keeps "the old value where no load was issued" alive through both conditionals -- 14
                 // v_mov per pair body and a second set of record registers (70 -> 57 VGPRs).
 #define SD_UNDEF4(q) asm volatile("" : "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w));
+#ifdef SD_EXP_LDSONLY // PERF-ONLY experiment (results wrong by construction): every hit is read from the window
+#define SD_FETCH(j, p, v) SD_UNDEF4(p) SD_UNDEF4(v)
+#define SD_USE(j, p, v)                                                        \
+    p = win[2 * ((unsigned)(j) % (unsigned)SL_DEAL_WINDOW)];                   \
+    v = win[2 * ((unsigned)(j) % (unsigned)SL_DEAL_WINDOW) + 1];               \
+    body(p, v);
+#else
 #define SD_FETCH(j, p, v)                                                      \
     SD_UNDEF4(p)                                                               \
     SD_UNDEF4(v)                                                               \
@@ -901,6 +908,7 @@ __global__ __launch_bounds__(SL_DEAL_THREADS) void k_force_dealt(DevParams P, Sw
         v = win[2 * ((j)-w0) + 1];                                             \
     }                                                                          \
     body(p, v);
+#endif
                 float4 p0 = make_float4(0, 0, 0, 0), v0 = p0, p1 = p0, v1 = p0;
                 int j0 = pop();
                 SD_FETCH(j0, p0, v0)
