@@ -200,6 +200,25 @@ def test_config5_67108864_matches_the_oracles_checksum():
     sim.close()
 
 
+def test_headline_config_in_eight_slabs_matches_the_oracles_checksums():
+    """The multi-GPU driver at full size: -n 4194304 -i random cut into 8 z-slabs (the RCCL path's stream
+    layout with event-ordered copies as messages, all slabs on this GPU) against the ORACLE's sha256 of
+    the positions at every golden step through step 100 -- the floor pile, pressure on, particles
+    migrating between slabs, the dealt force sweep on interior and boundary ranges."""
+    from cudafluidsimulator_amd import mgpu as M
+    g = _golden("random4194304_sha256.json")
+    mg = M.MultiGpuSimulator(sph.default_settings(g["n"], True), world=8, transport="streams")
+    mg.setup()
+    done = 0
+    for k in sorted(int(x) for x in g["steps"]):
+        for _ in range(k - done):
+            mg.simulate()
+        done = k
+        assert _sha(mg.download_state()["pos"]) == g["steps"][str(k)]["pos_sha256"], f"pos @ step {k}"
+    assert _sha(np.array(mg.getPosition())) == g["steps"][str(done)]["pos_sha256"], "getPosition()"
+    mg.close()
+
+
 def test_morton_order_at_full_size_matches_the_morton_keyed_oracle():
     """SPH_KEY_MORTON (BASELINE config 3's ordering) at n = 4,194,304 against the oracle run with the
     Morton key function: sha256 after steps 1 and 3 of a state that migrates along all three axes
