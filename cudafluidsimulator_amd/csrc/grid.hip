@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_gather_cells(
     // cursors are cleared for the density sweep that follows ...
     if (i < X.cursorWords) X.cursor[i] = 0ull;
     if (i < X.quietWords) X.quietClear[i] = 0u;
-    if (X.quietAll && i == 0) *X.quietAll = 1u;
+    if (X.quietAll && i == 0) X.quietAll[0] = X.quietAll[1] = 1u; // ("every owned row", "every halo row" is quiet)
     bool valid = i < n;
     uint32_t k = valid ? skeys[i] : 0xFFFFFFFFu;
     uint32_t kprev = __shfl_up(k, 1);

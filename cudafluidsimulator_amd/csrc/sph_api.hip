@@ -123,6 +123,7 @@ struct sph_handle {
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
     uint32_t *hitCount = nullptr;    // SPH_SWEEP_LIST: recorded hits per sorted row
+    int slabOwnedBegin = 0, slabOwnedEnd = 0; // rows of the last sph_slab_density (the rest of [0, n_all) is halo)
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
     float4 *quietVref = nullptr;     // ... its reference velocity (device; picked by the first sort pass) ...
     unsigned long long *calm = nullptr; // ... and one bit per sorted row "moves with it" (written by the gather launch)
@@ -389,7 +390,7 @@ int alloc_device(sph_handle *h) {
         const size_t quietWords = 2 * ((cap + 63) / 64) + 2;
         HIPCHK(h, hipMalloc(&h->quiet, quietWords * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->quiet, 0, quietWords * sizeof(uint32_t)));
-        HIPCHK(h, hipMalloc(&h->quietVref, 2 * sizeof(float4))); // [0] the reference velocity, [1].x the all-quiet word
+        HIPCHK(h, hipMalloc(&h->quietVref, 2 * sizeof(float4))); // [0] the reference velocity, [1].x the all-quiet word, [1].y the halo rows'
         HIPCHK(h, hipMemset(h->quietVref, 0, 2 * sizeof(float4)));
         HIPCHK(h, hipMalloc(&h->calm, ((cap + 63) / 64 + 1) * sizeof(unsigned long long)));
         HIPCHK(h, hipMemset(h->calm, 0, ((cap + 63) / 64 + 1) * sizeof(unsigned long long)));
@@ -755,7 +756,8 @@ SweepArgs make_sweep_args(sph_handle *h) {
     // so halo rows -- whose densities arrive after the density sweep -- stay "not quiet")
     A.quiet = (h->useQuiet && h->quiet) ? h->quiet : nullptr;
     A.calm = h->calm;
-    A.quietAll = (A.quiet && !h->external) ? reinterpret_cast<uint32_t *>(h->quietVref + 1) : nullptr;
+    A.quietAll = A.quiet ? reinterpret_cast<uint32_t *>(h->quietVref + 1) : nullptr;
+    A.quietHalo = nullptr; // (slab launches next to a halo layer set it: slab_halo_quiet)
     A.rhoToVel4 = h->external ? 1 : 0;
     A.listHead = reinterpret_cast<const int *>(h->cellRange);
     A.listNext = reinterpret_cast<const int *>(h->ws.vals[0]);
@@ -773,7 +775,7 @@ GatherExtras gather_extras(sph_handle *h) {
     if (h->quiet && h->useQuiet) {
         X.vref = h->quietVref;
         X.calm = h->calm;
-        if (!h->external) X.quietAll = reinterpret_cast<uint32_t *>(h->quietVref + 1);
+        X.quietAll = reinterpret_cast<uint32_t *>(h->quietVref + 1);
         if (h->external) { // single domain: the density sweep rewrites every word each step
             X.quietClear = h->quiet;
             X.quietWords = (int)(2 * (((size_t)h->cap + 63) / 64) + 2);
@@ -987,6 +989,8 @@ int sph_slab_density(sph_handle *h, int buf, int i_begin, int i_end, int n_all) 
     A.i_begin = i_begin;
     A.i_end = i_end;
     A.i_origin = i_begin & ~63; // hit-stream waves = whole words of the zero-pair filter's bit array
+    h->slabOwnedBegin = i_begin;
+    h->slabOwnedEnd = i_end;
     A.n_all = n_all;
     A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
     A.tileRotate = slab_rotate(h);
@@ -1012,6 +1016,7 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all) {
     A.i_begin = i_begin;
     A.i_end = i_end;
     A.i_origin = i_begin & ~63;
+    A.quietAll = nullptr; // (rows next to the halo layers, whose quiet bits nobody computed here: no all-quiet skip)
     A.patchHalo = 1;
     A.n_all = n_all;
     A.tileChunk = tile_chunk(h, i_end - i_begin, h->zLayers);
@@ -1073,6 +1078,18 @@ int sph_slab_force_ranges(sph_handle *h, int buf, int i_origin, int a0, int b0, 
         A.patchHalo = 0;
         A.n_all = n_all;
         A.tileRotate = slab_rotate(h);
+        if (A.quietAll) {
+            // the last launch of the step holds the rows next to the halo layers (exchange B is through on this
+            // stream): "every row is quiet" needs the halo rows' word too.  Earlier launches are interior rows by
+            // contract -- every neighbour an owned row.
+            if (last && h->opt.sweep == SPH_SWEEP_LIST && h->slabOwnedEnd > h->slabOwnedBegin && h->slabOwnedEnd <= n_all) {
+                uint32_t *halo = A.quietAll + 1;
+                sph_launch_halo_quiet(h->pv8, h->slabOwnedBegin, h->slabOwnedEnd, n_all, h->quietVref, A.quietAll, halo, s);
+                A.quietHalo = halo;
+            } else if (last) {
+                A.quietAll = nullptr;
+            }
+        }
         A.force_out = nullptr;
         PairEvent *pe = nullptr;
         if ((rc = pair_begin(h, &h->kt.force, &pe, s))) return rc;

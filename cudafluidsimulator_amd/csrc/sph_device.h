@@ -108,7 +108,8 @@ struct GatherExtras {
     int *bounds = nullptr;                // slab path: bounds[t] = #keys < thr.v[t], bounds[nthr] = n
     const float4 *vref = nullptr;         // zero-pair filter: the reference velocity (picked by the first sort pass) ...
     unsigned long long *calm = nullptr;   // ... and one bit per sorted row "moves with it", a 64-bit word per 64 rows
-    uint32_t *quietAll = nullptr;         // single domain: the "every row is quiet" word is set to 1 here
+    uint32_t *quietAll = nullptr;         // the "every (owned) row is quiet" word and, next to it, the "every halo row is
+                                          // quiet" word (slabs) are set to 1 here
     uint32_t *quietClear = nullptr;       // slab path: the filter's bit array is cleared here (halo rows stay "not quiet") ...
     int quietWords = 0;                   // ... this many 32-bit words
     Thresholds thr{};
@@ -178,14 +179,18 @@ struct SweepArgs {
                                       // has no pressure and moves with the reference velocity *quietVref; a hit between
                                       // two such rows adds exactly +-0 to the force and is dropped unread
     const unsigned long long *calm;   // bit j: sorted row j moves with the reference velocity (written by the gather launch)
-    uint32_t *quietAll;               // single domain (else null): 1 while EVERY row of this step is quiet -- set by the
+    uint32_t *quietAll;               // 1 while EVERY row of this step's density sweep (slabs: every owned row) is quiet -- set by the
                                       // gather launch, cleared by the density sweep's first non-quiet row; the force
                                       // sweep then has no pair to evaluate and does not read its hit stream at all
+    const uint32_t *quietHalo;        // slabs, launches that hold rows next to a halo layer (else null): 1 while every
+                                      // HALO row of this step is quiet too (k_halo_quiet, after exchange B)
     int rhoToVel4;                    // list sweep: also store rho in vel4.w (slab halo exchange B)
     // SPH_SWEEP_LINKED: per-cell linked lists over the UNSORTED streams
     const int *listHead;              // [numCells] first particle of the cell or -1
     const int *listNext;              // [n] next particle of the same cell or -1
 };
+void sph_launch_halo_quiet(const float4 *pv8, int lo_end, int hi_begin, int n_all, const float4 *vref,
+                           const uint32_t *ownedQuiet, uint32_t *haloQuiet, hipStream_t s);
 // ---- linked-list backend (sweeps_linked.hip) ----
 void sph_launch_link_build(const DevParams &P, const float4 *pos4, int *head, int *next, int n,
                            hipStream_t s);

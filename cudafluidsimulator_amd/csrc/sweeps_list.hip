@@ -518,7 +518,8 @@ void k_force_list(DevParams P, SweepArgs A) {
     if (baseq == SL_NONE) return;
     // Every row of the domain quiet (fluid in free fall): no pair adds anything -- the hit stream is
     // not even read, the sweep is the integration alone.
-    const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u;
+    const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u &&
+                          (!A.quietHalo || __builtin_amdgcn_readfirstlane(*A.quietHalo) != 0u);
     if (!allQuiet) {
         // Bit cursor.  (jb, m): first candidate and remaining bits of the current
         // pair; (jq, mq): the pairs of the last quad loaded.  A lane's sequence ends
@@ -790,7 +791,8 @@ __global__ __launch_bounds__(SL_DEAL_THREADS) void k_force_dealt(DevParams P, Sw
     // ---- the window ----
     // Every row of the domain quiet (fluid in free fall): no pair adds anything -- the hit stream is not even
     // read, the sweep is the integration alone.
-    const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u;
+    const bool allQuiet = A.quietAll && __builtin_amdgcn_readfirstlane(*A.quietAll) != 0u &&
+                          (!A.quietHalo || __builtin_amdgcn_readfirstlane(*A.quietHalo) != 0u);
     const int w0 = max(R0 - (SL_WINDOW - SPH_WAVE) / 2, 0);
     int wlen = max(min(SL_DEAL_WINDOW, A.n_all - w0), 0);
     {
@@ -936,6 +938,28 @@ __global__ __launch_bounds__(SL_DEAL_THREADS) void k_force_dealt(DevParams P, Sw
             store_particle(A, i, pi, vx, vy, vz, vi.w, F);
         }
     }
+}
+
+// Slabs: the halo rows' half of "every row is quiet".  A slab's density sweep clears *quietAll at its first
+// owned row that is not quiet; the halo rows' densities arrive with exchange B, so their test -- the same one:
+// no pressure, the slab's reference velocity -- runs afterwards, on the stream of the force launch that
+// holds the rows next to the halo layers.  (Free fall, N = 8 slabs of the headline run: that launch then
+// skips its hit stream like the single domain's.)
+__global__ __launch_bounds__(256) void k_halo_quiet(const float4 *__restrict__ pv8, int lo_end, int hi_begin, int n_all,
+                                                    const float4 *__restrict__ vref, const uint32_t *__restrict__ ownedQuiet,
+                                                    uint32_t *__restrict__ haloQuiet) {
+    if (*ownedQuiet == 0u) return; // (nobody will ask)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lo_end + (n_all - hi_begin)) return;
+    const int j = t < lo_end ? t : hi_begin + (t - lo_end);
+    const float4 v = pv8[2 * (size_t)j + 1], r = *vref;
+    const float prs = fmaxf(0.f, SPH_GAS_CONSTANT * (v.w - SPH_REST_DENSITY));
+    if (!(prs == 0.f && v.x == r.x && v.y == r.y && v.z == r.z)) *haloQuiet = 0u; // (every writer writes the same value)
+}
+void sph_launch_halo_quiet(const float4 *pv8, int lo_end, int hi_begin, int n_all, const float4 *vref,
+                           const uint32_t *ownedQuiet, uint32_t *haloQuiet, hipStream_t s) {
+    const int rows = lo_end + (n_all - hi_begin);
+    if (rows > 0) k_halo_quiet<<<(rows + 255) / 256, 256, 0, s>>>(pv8, lo_end, hi_begin, n_all, vref, ownedQuiet, haloQuiet);
 }
 
 // SPH_FLAG_COUNT_PAIRS only (bench.py's untimed counting replay): pair bodies the force

@@ -242,7 +242,10 @@ int sph_slab_force(sph_handle *h, int buf, int i_begin, int i_end, int n_all);
  * neighbours / copies them to pinned memory.  sph_slab_force_ranges runs the force +
  * integration sweep for row ranges of the owned range whose hit stream was recorded
  * by sph_slab_density(buf, i_origin, ...): the interior rows can run while the halo
- * densities are still in flight, the two boundary layers after sph_slab_patch_halo. */
+ * densities are still in flight, the two boundary layers after sph_slab_patch_halo.
+ * Every launch before the one flagged last_launch_of_the_step must hold INTERIOR rows only
+ * (every neighbour an owned row): the last one also tests the halo rows for the zero-pair
+ * filter's "every row is quiet" shortcut, the earlier ones rely on the owned rows alone. */
 void *sph_get_stream(sph_handle *h);
 int sph_slab_partition_async(sph_handle *h, int src_buf, int src_offset, int count,
                              const uint32_t *thresholds, int nthr, void *bounds_dev_out);
