@@ -893,6 +893,7 @@ int sph_slab_sort_async(sph_handle *h, int src_buf, int src_offset, int count,
     h->sorted = src_buf ^ 1;
     h->sortedKeyBuf = res;
     h->gridValid = true;
+    h->slabOwnedEnd = h->slabOwnedBegin = 0; // (a new sorted array: no density sweep has vouched for any row of it yet)
     return SPH_OK;
 }
 
