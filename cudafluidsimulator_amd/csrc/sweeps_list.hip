@@ -380,7 +380,10 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
                 // trip -- 60 % of the trips at step 1, 92 % at step 100; one pointer select per lane instead of a
                 // compare and a select per candidate, 6 of 73 VALU instructions -- is bit-identical and SLOWER:
                 // density 0.753 vs 0.70 ms over the 100 steps; the extra ballot and branch per trip cost more
-                // than the selects)
+                // than the selects.  The same trips as a first phase of FIXED trip count per run -- no vote either, a
+                // lane without a range parked on the sentinel: 80 VGPRs + 24 bytes of scratch at six waves, 0.688-0.706 vs
+                // 0.704-0.709; at five waves 0.711-0.718.  Round 2 measured that form at +0.5 % too: the loop is not
+                // bound by the instructions these forms remove)
                 if (R.staged) {
                     for (; __ballot(k < len); k += SW_UNROLL) {
                         float4 pj[SW_UNROLL];
