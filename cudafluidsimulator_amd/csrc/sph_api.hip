@@ -122,6 +122,7 @@ struct sph_handle {
     SphKernelTimes kt{};
     float4 *pv8 = nullptr;
     uint32_t *maskPool = nullptr, *maskOff = nullptr; // SPH_SWEEP_LIST
+    uint32_t *noneList = nullptr;    // SPH_SWEEP_LIST: waves without a stream this step (pool exhausted)
     uint32_t *hitCount = nullptr;    // SPH_SWEEP_LIST: recorded hits per sorted row
     int slabOwnedBegin = 0, slabOwnedEnd = 0; // rows of the last sph_slab_density (the rest of [0, n_all) is halo)
     uint32_t *quiet = nullptr;       // SPH_SWEEP_LIST: one bit per sorted row, the force sweep's zero-pair filter
@@ -382,6 +383,7 @@ int alloc_device(sph_handle *h) {
         const size_t hdrWords = 2 * ((cap + 63) / 64 + 1);
         HIPCHK(h, hipMalloc(&h->maskOff, hdrWords * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(h->maskOff, 0xFF, hdrWords * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(&h->noneList, hdrWords * sizeof(uint32_t))); // (>= one entry per wave)
         HIPCHK(h, hipMalloc(&h->maskCursor, kCursorBytes));
         HIPCHK(h, hipMemset(h->maskCursor, 0, kCursorBytes));
         HIPCHK(h, hipMalloc(&h->hitCount, (cap + 64) * sizeof(uint32_t)));
@@ -748,6 +750,7 @@ SweepArgs make_sweep_args(sph_handle *h) {
     A.tileRotate = h->tileRotate > 0 ? h->tileRotate : 0;
     A.maskPool = h->maskPool;
     A.maskOff = h->maskOff;
+    A.noneList = h->noneList;
     A.hitCount = h->hitCount;
     A.maskCursor = h->maskCursor;
     A.maskCapacity = h->maskCapacity;
@@ -1286,6 +1289,7 @@ void sph_destroy(sph_handle *h) {
     if (h->pv8) (void)hipFree(h->pv8);
     if (h->maskPool) (void)hipFree(h->maskPool);
     if (h->maskOff) (void)hipFree(h->maskOff);
+    if (h->noneList) (void)hipFree(h->noneList);
     if (h->hitCount) (void)hipFree(h->hitCount);
     if (h->maskCursor) (void)hipFree(h->maskCursor);
     if (h->quiet) (void)hipFree(h->quiet);

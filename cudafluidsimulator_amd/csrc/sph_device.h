@@ -172,7 +172,9 @@ struct SweepArgs {
     uint32_t *maskPool;               // pool of quads: two (first candidate, 32-bit mask) pairs each
     uint32_t *maskOff;                // per 64-particle wave: {first quad or ~0u, quads per lane}
     uint32_t *hitCount;               // per sorted row: hits the density sweep recorded (the force sweep deals rows to lanes by it)
-    unsigned long long *maskCursor;   // quads handed out this step, per sub-pool: [SL_POOL_SHARDS][SL_CURSOR_STRIDE]
+    unsigned long long *maskCursor;   // quads handed out this step, per sub-pool: [SL_POOL_SHARDS][SL_CURSOR_STRIDE];
+                                      // word 1 (cleared with them): waves that found their sub-pool exhausted ...
+    uint32_t *noneList;               // ... and their numbers, in arrival order (k_force_fallback walks this list)
     unsigned long long maskCapacity;  // pool size in quads
     float4 *pv8;                      // interleaved (pos4, vel4) copy of the sorted streams
     uint32_t *quiet;                  // zero-pair filter (may be null = off): bit j of this array is set when sorted row j

@@ -192,6 +192,7 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
     if (lane == 0 && anyValid) {
         A.maskOff[2 * (size_t)wv] = ok ? (uint32_t)base : SL_NONE;
         A.maskOff[2 * (size_t)wv + 1] = (uint32_t)Q;
+        if (!ok) A.noneList[atomicAdd(A.maskCursor + 1, 1ull)] = (uint32_t)wv; // (for k_force_fallback)
     }
     uint4 *const myq = reinterpret_cast<uint4 *>(A.maskPool) + (ok ? base : 0ull) + lane;
     if (A.pairCounter) { // sharded like the stamps: one address would serialise the waves
@@ -1012,15 +1013,19 @@ void sph_launch_density_list(const DevParams &P, const SweepArgs &A, int mathMod
 }
 
 // Particles whose wave found the mask pool exhausted in the density sweep: test
-// every candidate, like the check path.  Launched after k_force_list every step;
-// waves with nothing to do leave after one load.
+// every candidate, like the check path.  Launched after the force sweep every step with a
+// small fixed grid that walks the density sweep's list of such waves (none in the runs
+// measured: the launch is a handful of waves reading one word -- a launch over every row
+// that checked maskOff[] cost 8 us per step at n = 4 M, 4-7 us of a 220 us slab step).
+#define SL_FALLBACK_BLOCKS 512
 template <bool FAST, bool SLIM>
-__global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, SweepArgs A) {
-    // one launch over the hull of the (up to two) row ranges of the force launch
-    const int i = A.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inRange = i < A.i_end || (i >= A.i_begin2 && i < A.i_end2);
-    const bool mine = inRange && A.maskOff[2 * (size_t)((i - A.i_origin) >> 6)] == SL_NONE;
-    if (!__ballot(mine)) return;
+__global__ __launch_bounds__(SPH_WAVE) void k_force_fallback(DevParams P, SweepArgs A) {
+    const unsigned count = (unsigned)A.maskCursor[1];
+    for (unsigned idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    // the rows of this force launch (up to two ranges) among the wave's 64
+    const int i = A.i_origin + (int)A.noneList[idx] * SPH_WAVE + (int)threadIdx.x;
+    const bool mine = (i >= A.i_begin && i < A.i_end) || (i >= A.i_begin2 && i < A.i_end2);
+    if (!__ballot(mine)) continue;
     const int iSafe = mine ? i : A.i_begin;
     float4 pi = A.pv8[2 * (size_t)iSafe];
     const float4 vi = A.pv8[2 * (size_t)iSafe + 1];
@@ -1039,6 +1044,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_force_fallback(DevParams P, Swee
         float vx = vi.x, vy = vi.y, vz = vi.z;
         integrate_particle(P, pi, vx, vy, vz, F, vi.w);
         store_particle(A, i, pi, vx, vy, vz, vi.w, F);
+    }
     }
 }
 
@@ -1083,17 +1089,16 @@ void sph_launch_force_list(const DevParams &P, const SweepArgs &A, int mathMode,
     };
     B.nblk1 = blocks_of(B.i_begin, B.i_end);
     const int fblocks = B.nblk1 + blocks_of(B.i_begin2, B.i_end2);
-    const int hullEnd = B.i_end2 > B.i_begin2 ? B.i_end2 : B.i_end;
-    const int blocks = (hullEnd - B.i_begin + SW_THREADS - 1) / SW_THREADS;
+    const int blocks = SL_FALLBACK_BLOCKS;
     if (mathMode == 1) {
         SL_FORCE_KERNEL<true, true><<<fblocks, threads, 0, s>>>(P, B);
-        k_force_fallback<true, true><<<blocks, SW_THREADS, 0, s>>>(P, B);
+        k_force_fallback<true, true><<<blocks, SPH_WAVE, 0, s>>>(P, B);
     } else if (P.slimDiv) { // the reference's h and kernel coefficients (sweep_common.h)
         SL_FORCE_KERNEL<false, true><<<fblocks, threads, 0, s>>>(P, B);
-        k_force_fallback<false, true><<<blocks, SW_THREADS, 0, s>>>(P, B);
+        k_force_fallback<false, true><<<blocks, SPH_WAVE, 0, s>>>(P, B);
     } else {
         SL_FORCE_KERNEL<false, false><<<fblocks, threads, 0, s>>>(P, B);
-        k_force_fallback<false, false><<<blocks, SW_THREADS, 0, s>>>(P, B);
+        k_force_fallback<false, false><<<blocks, SPH_WAVE, 0, s>>>(P, B);
     }
 #undef SL_FORCE_KERNEL
 }
