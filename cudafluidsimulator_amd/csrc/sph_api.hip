@@ -96,6 +96,7 @@ struct sph_handle {
     bool graphEvPending[2] = {false, false};
     bool useGraph = false, capturing = false;
     int graphKeyBuf = 0;
+    int graphCellCur[2] = {0, 0};   // the cell table each slot's graphs were captured with (what a click after a replay walks)
     hipEvent_t computeDone[2] = {nullptr, nullptr}, copyDone[2] = {nullptr, nullptr};
     bool copyPending[2] = {false, false};
     // Read-back of a TIMED step through an SDMA engine (hsa_amd_memory_async_copy) instead of the HIP runtime's
@@ -1530,6 +1531,7 @@ int capture_step_graph(sph_handle *h, int slot) {
     }
     h->capturing = false;
     h->graphKeyBuf = h->sortedKeyBuf;
+    h->graphCellCur[slot] = h->cellCur;
     // the captured calls only recorded work: restore the host-side state they advanced
     h->phase = phase0;
     h->cur = cur0;
@@ -1596,6 +1598,10 @@ int sph_step(sph_handle *h, SphTimes *times) {
                 h->sorted = h->cur ^ 1;
                 h->sortedKeyBuf = h->graphKeyBuf;
                 h->gridValid = true;
+                h->cellCur = h->graphCellCur[slot];
+                h->cellRange = h->cellTable[h->cellCur];
+                h->clickTable = h->cellRange;
+                h->clickValid = true;
                 h->cur = h->sorted ^ 1;
                 h->phase = 3;
             } else {

@@ -540,6 +540,26 @@ def test_step_graphs_equal_the_oracle(n, monkeypatch):
     sim.close()
 
 
+def test_click_after_graph_replays_walks_that_steps_grid(monkeypatch):
+    """SPH_GRAPH=1 and the click impulse: the two read-back slots' graphs were captured with different
+    cell tables (the grid build alternates between two), so after a REPLAY the click has to walk the
+    table of the replayed slot, not the one the last capture left behind.  Clicks after steps 3, 4 and 7
+    (both slots, all replays) against the oracle."""
+    monkeypatch.setenv("SPH_GRAPH", "1")
+    pos, vel = random_state(30000, 21, lo=1.0, hi=9.0, vmax=0.1)
+    sim, ref = make_pair(len(pos), False, pos=pos, vel=vel)
+    clicks = {3: (420, 333), 4: (250, 200), 7: (590, 440)}
+    for step in range(1, 9):
+        if step in clicks:
+            sim.mouseClicked, sim.clickCoords = True, clicks[step]
+        sim.simulate()
+        ref.step()
+        if step in clicks:
+            ref.click(*clicks[step])
+        compare_state(sim, ref, f"graph mode, step {step}")
+    sim.close()
+
+
 @pytest.mark.parametrize("sweep", ["list", "lds"])
 def test_mapped_positions_after_every_step(sweep):
     """SPH_FLAG_MAPPED_POSITIONS (zero-copy display path): the force sweep
