@@ -79,6 +79,7 @@ struct sph_handle {
     StepEvents *aheadEv = nullptr;
     float *devPos[2] = {nullptr, nullptr};
     float *hostPos = nullptr; // pinned, n*3
+    bool hostPosIsInit = false; // setup() restored the initial state on the device: getPosition() fetches it on demand
     // Pinned staging for state uploads (two halves, ping-pong).  A hipMemcpy from pageable
     // memory makes the runtime pin and later unpin the caller's pages; the unpin is deferred
     // and stalls the GPU's queues for 6-28 ms some time AFTER the call returned -- inside the
@@ -710,6 +711,10 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     HIPCHK(h, hipDeviceSynchronize());
     h->zLayers = zmax >= zmin ? zmax - zmin + 1 : 0;
     state_replaced(h);
+    // getPosition() right after an upload shows the uploaded state (like setup(): simulator.cu:430-456 fills the
+    // host array it hands out)
+    h->hostPosIsInit = false;
+    if (h->hostPos && n > 0) memcpy(h->hostPos, pos, (size_t)n * 3 * sizeof(float));
     return SPH_OK;
 }
 
@@ -1329,6 +1334,7 @@ int sph_setup(sph_handle *h) {
         HIPCHK(h, hipStreamSynchronize(h->compute));
         h->zLayers = h->initZLayers;
         state_replaced(h);
+        h->hostPosIsInit = true; // (getPosition() before the next step: sph_positions_host copies them then)
         return SPH_OK;
     }
     std::vector<float> pos((size_t)(n > 0 ? n : 1) * 3, 0.f);
@@ -1451,6 +1457,7 @@ int sph_phase_force(sph_handle *h) {
     HIPCHK(h, hipGetLastError());
     h->cur = h->sorted ^ 1; // new state, still in this step's sorted order
     h->phase = 3;
+    h->hostPosIsInit = false;
     h->clickTable = h->cellRange;
     h->clickValid = h->opt.sweep != SPH_SWEEP_LINKED;
     return SPH_OK;
@@ -1604,6 +1611,7 @@ int sph_step(sph_handle *h, SphTimes *times) {
                 h->clickValid = true;
                 h->cur = h->sorted ^ 1;
                 h->phase = 3;
+                h->hostPosIsInit = false;
             } else {
                 (void)hipGetLastError();
                 h->useGraph = false;
@@ -1712,6 +1720,15 @@ const float *sph_positions_host(sph_handle *h) {
         return nullptr;
     }
     if (sdma_wait(h, 0) || sdma_wait(h, 1)) return nullptr;
+    if (h->hostPosIsInit && h->initPos4 && h->hostPos && h->n > 0) {
+        // the initial streams are in id order: x, y, z of every 16-byte row
+        if (hipMemcpy2D(h->hostPos, 3 * sizeof(float), h->initPos4, sizeof(float4), 3 * sizeof(float), (size_t)h->n,
+                        hipMemcpyDeviceToHost) != hipSuccess) {
+            h->err = "copy of the initial positions failed";
+            return nullptr;
+        }
+    }
+    h->hostPosIsInit = false;
     report_oob(h);
     return h->hostPos;
 }
@@ -1811,6 +1828,18 @@ int sph_load_state(sph_handle *h, const char *path) {
     h->sorted = -1;
     h->stepIndex = hd.stepIndex;
     h->copyPending[0] = h->copyPending[1] = false;
+    (void)sdma_wait(h, 0);
+    (void)sdma_wait(h, 1);
+    h->rbDeferredSlot = -1;
+    h->hostPosIsInit = false;
+    if (h->hostPos) // getPosition() shows the loaded state (id order)
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t id;
+            memcpy(&id, &p4[i].w, 4);
+            h->hostPos[3 * (size_t)id] = p4[i].x;
+            h->hostPos[3 * (size_t)id + 1] = p4[i].y;
+            h->hostPos[3 * (size_t)id + 2] = p4[i].z;
+        }
     return SPH_OK;
 }
 

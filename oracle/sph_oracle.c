@@ -439,6 +439,9 @@ void oracle_sim_setup(OracleSim *m) {
         oracle_init_positions_dense(&m->s, m->pos);
     }
     memset(m->vel, 0, sizeof(float) * 3 * (size_t)m->n);
+    /* a fresh particle array: simulator.cu:414-422 cudaMemset()s it, density and pressure are 0 until a step */
+    memset(m->rho, 0, sizeof(float) * (size_t)m->n);
+    memset(m->prs, 0, sizeof(float) * (size_t)m->n);
     for (int i = 0; i < m->n; i++) m->id[i] = (uint32_t)i;
 }
 
@@ -446,6 +449,8 @@ void oracle_sim_upload(OracleSim *m, const float *pos, const float *vel) {
     memcpy(m->pos, pos, sizeof(float) * 3 * (size_t)m->n);
     if (vel) memcpy(m->vel, vel, sizeof(float) * 3 * (size_t)m->n);
     else memset(m->vel, 0, sizeof(float) * 3 * (size_t)m->n);
+    memset(m->rho, 0, sizeof(float) * (size_t)m->n); /* (a new state, like setup()) */
+    memset(m->prs, 0, sizeof(float) * (size_t)m->n);
     for (int i = 0; i < m->n; i++) m->id[i] = (uint32_t)i;
 }
 

@@ -1,0 +1,122 @@
+"""Random sequences of the C-ABI's calls under random library knobs, against the oracle after every step.
+Each seed draws the sweep family, the handle flags, the environment knobs that change the step's control flow
+(graph replay, the grid build queued ahead, the read-back path, the zero-pair filter, the pair body's divide
+chains) and ~30 operations: simulate / simulateAndTime / the four phases by hand / click / getPosition /
+upload of a new state / setup() / save + load of a snapshot.  Strict mode: every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+import cudafluidsimulator_amd as sph
+from cudafluidsimulator_amd import _lib
+from helpers import assert_bit_equal, clustered_state, random_state
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+KNOBS = {"SPH_GRAPH": ("0", "1"), "SPH_PIPELINE": ("0", "1"), "SPH_READBACK_SDMA": ("0", "1"),
+         "SPH_ZERO_PAIR_FILTER": ("0", "1"), "SPH_SLIM_DIV": ("0", "1"), "SPH_XCD_ROTATE": ("0", "1", "5")}
+
+
+def check(sim, ref, what):
+    g, r = sim.download_state(), ref.download()
+    for k in ("pos", "vel", "rho"):
+        assert_bit_equal(g[k], r[k], f"{what}: {k}")
+    assert_bit_equal(np.array(sim.getPosition()), r["pos"], f"{what}: getPosition()")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_call_sequences_stay_on_the_oracle(seed, monkeypatch, tmp_path):
+    rng = np.random.default_rng(1000 + seed)
+    sweep = ["list", "list", "lds", "direct"][rng.integers(4)]
+    flags = int(rng.choice([0, 0, _lib.SPH_FLAG_MAPPED_POSITIONS])) if sweep != "direct" else 0
+    env = {k: str(rng.choice(v)) for k, v in KNOBS.items()}
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = int(rng.choice([1500, 6000, 20000]))
+    random_init = bool(rng.integers(2))
+    sim = sph.Simulator(sph.default_settings(n, random_init), sweep=sweep, flags=flags)
+    ref = O.OracleSim(n, random_init)
+    sim.setup()
+    ref.setup()
+    what = f"seed {seed} ({sweep}, flags {flags}, {env}, n {n})"
+    t = sph.Times()
+    steps = 0
+    for op_no in range(30):
+        op = rng.choice(["step", "step", "step", "timed", "timed", "phases", "click", "peek", "upload", "setup", "snapshot"])
+        tag = f"{what}, op {op_no} {op}"
+        if op == "step":
+            sim.simulate(); ref.step(); steps += 1
+        elif op == "timed":
+            sim.simulateAndTime(t); ref.step(); steps += 1
+        elif op == "phases":
+            for ph in ("grid", "density", "force", "readback"):
+                sim.phase(ph)
+            ref.step(); steps += 1
+        elif op == "click":
+            xy = (int(rng.integers(100, 700)), int(rng.integers(100, 500)))
+            sim.mouseClicked, sim.clickCoords = True, xy
+            sim.simulate(); ref.step(); ref.click(*xy); steps += 1
+        elif op == "peek":
+            assert_bit_equal(np.array(sim.getPosition()), ref.download()["pos"], tag)
+            continue
+        elif op == "upload":
+            pos, vel = (clustered_state if rng.integers(2) else random_state)(n, int(rng.integers(1 << 30)))
+            sim.upload_state(pos, vel); ref.upload(pos, vel)
+        elif op == "setup":
+            sim.setup(); ref.setup()
+        elif op == "snapshot":
+            path = tmp_path / f"s{op_no}.sphsnap"
+            sim.save_state(path)
+            sim.simulate()                       # (moves on, then comes back to the snapshot)
+            sim.load_state(path)
+        check(sim, ref, tag)
+    sim.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_call_sequences_over_slabs_stay_on_the_oracle(seed, monkeypatch):
+    """The same for the multi-GPU driver (all slabs on this GPU): world size, transport, re-cut period and the
+    per-slab knobs drawn at random; steps, timed steps, clicks, getPosition(), uploads and setup() against the
+    oracle after every operation."""
+    from cudafluidsimulator_amd import mgpu as M
+    rng = np.random.default_rng(5000 + seed)
+    env = {k: str(rng.choice(v)) for k, v in KNOBS.items() if k in ("SPH_ZERO_PAIR_FILTER", "SPH_SLIM_DIV", "SPH_XCD_ROTATE")}
+    env["SPH_MGPU_THREADS"] = str(rng.integers(2))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    world = int(rng.integers(2, 7))
+    transport = ["loopback", "streams", "rccl_self"][rng.integers(3)] if world <= 3 else ["loopback", "streams"][rng.integers(2)]
+    recut = int(rng.choice([0, 0, 2, 5]))
+    n = int(rng.choice([6000, 20000, 60000]))
+    random_init = bool(rng.integers(2))
+    mg = M.MultiGpuSimulator(sph.default_settings(n, random_init), world=world, transport=transport, recut_every=recut)
+    ref = O.OracleSim(n, random_init)
+    mg.setup()
+    ref.setup()
+    what = f"seed {seed} ({world} slabs, {transport}, recut {recut}, {env}, n {n})"
+    t = sph.Times()
+    for op_no in range(24):
+        op = rng.choice(["step", "step", "step", "timed", "click", "peek", "upload", "setup"])
+        tag = f"{what}, op {op_no} {op}"
+        if op == "step":
+            mg.simulate(); ref.step()
+        elif op == "timed":
+            mg.simulateAndTime(t); ref.step()
+        elif op == "click":
+            xy = (int(rng.integers(100, 700)), int(rng.integers(100, 500)))
+            mg.mouseClicked, mg.clickCoords = True, xy
+            mg.simulate(); ref.step(); ref.click(*xy)
+        elif op == "peek":
+            assert_bit_equal(np.array(mg.getPosition()), ref.download()["pos"], tag)
+            continue
+        elif op == "upload":
+            # (a moving cloud inside the box: z-layers 10..89 occupied, like the reference's random fill)
+            pos, vel = random_state(n, int(rng.integers(1 << 30)), lo=1.0, hi=9.0, vmax=0.5)
+            mg.upload_state(pos, vel); ref.upload(pos, vel)
+        elif op == "setup":
+            mg.setup(); ref.setup()
+        g, r = mg.download_state(), ref.download()
+        assert g["written"] == n
+        for k in ("pos", "vel", "rho"):
+            assert_bit_equal(g[k], r[k], f"{tag}: {k}")
+        assert_bit_equal(np.array(mg.getPosition()), r["pos"], f"{tag}: getPosition()")
+    mg.close()
