@@ -23,8 +23,10 @@ def check(sim, ref, what):
     assert_bit_equal(np.array(sim.getPosition()), r["pos"], f"{what}: getPosition()")
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", list(range(40)) + [100, 101, 102, 200])
 def test_random_call_sequences_stay_on_the_oracle(seed, monkeypatch, tmp_path):
+    """seeds >= 100: n = 262,144 (several sort tiles, the grid build queued ahead by default), seed 200:
+    n = 1,600,000 (past the size at which the sort switches to 4096-key tiles and pipelining goes off)."""
     rng = np.random.default_rng(1000 + seed)
     sweep = ["list", "list", "lds", "direct"][rng.integers(4)]
     flags = int(rng.choice([0, 0, _lib.SPH_FLAG_MAPPED_POSITIONS])) if sweep != "direct" else 0
@@ -32,6 +34,9 @@ def test_random_call_sequences_stay_on_the_oracle(seed, monkeypatch, tmp_path):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = int(rng.choice([1500, 6000, 20000]))
+    n_ops = 30
+    if seed >= 100:
+        n, n_ops = (1600000, 8) if seed >= 200 else (262144, 14)
     random_init = bool(rng.integers(2))
     sim = sph.Simulator(sph.default_settings(n, random_init), sweep=sweep, flags=flags)
     ref = O.OracleSim(n, random_init)
@@ -40,7 +45,7 @@ def test_random_call_sequences_stay_on_the_oracle(seed, monkeypatch, tmp_path):
     what = f"seed {seed} ({sweep}, flags {flags}, {env}, n {n})"
     t = sph.Times()
     steps = 0
-    for op_no in range(30):
+    for op_no in range(n_ops):
         op = rng.choice(["step", "step", "step", "timed", "timed", "phases", "click", "peek", "upload", "setup", "snapshot"])
         tag = f"{what}, op {op_no} {op}"
         if op == "step":
