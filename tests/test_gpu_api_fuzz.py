@@ -77,7 +77,7 @@ def test_random_call_sequences_stay_on_the_oracle(seed, monkeypatch, tmp_path):
     sim.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(28))
 def test_random_call_sequences_over_slabs_stay_on_the_oracle(seed, monkeypatch):
     """The same for the multi-GPU driver (all slabs on this GPU): world size, transport, re-cut period and the
     per-slab knobs drawn at random; steps, timed steps, clicks, getPosition(), uploads and setup() against the
@@ -91,7 +91,7 @@ def test_random_call_sequences_over_slabs_stay_on_the_oracle(seed, monkeypatch):
     world = int(rng.integers(2, 7))
     transport = ["loopback", "streams", "rccl_self"][rng.integers(3)] if world <= 3 else ["loopback", "streams"][rng.integers(2)]
     recut = int(rng.choice([0, 0, 2, 5]))
-    n = int(rng.choice([6000, 20000, 60000]))
+    n = int(rng.choice([6000, 20000, 60000] if seed < 16 else [300, 2000, 6000]))  # (seeds >= 16: nearly empty slabs)
     random_init = bool(rng.integers(2))
     mg = M.MultiGpuSimulator(sph.default_settings(n, random_init), world=world, transport=transport, recut_every=recut)
     ref = O.OracleSim(n, random_init)
