@@ -46,9 +46,26 @@ def test_random_call_sequences_stay_on_the_oracle(seed, monkeypatch, tmp_path):
     t = sph.Times()
     steps = 0
     for op_no in range(n_ops):
-        op = rng.choice(["step", "step", "step", "timed", "timed", "phases", "click", "peek", "upload", "setup", "snapshot"])
+        op = rng.choice(["step", "step", "step", "timed", "timed", "phases", "click", "peek", "upload", "setup", "snapshot",
+                         "misuse"])
         tag = f"{what}, op {op_no} {op}"
-        if op == "step":
+        if op == "misuse":
+            # calls that must fail loudly and leave the simulator as it was
+            kind = rng.integers(5)
+            with pytest.raises(sph.SphError):
+                if kind == 0:
+                    sim.phase(["force", "readback"][rng.integers(2)])                  # phases out of order
+                elif kind == 1:
+                    sim.upload_state(np.zeros((n + 1, 3), np.float32) + 5.0)           # wrong particle count
+                elif kind == 2:
+                    bad = np.full((n, 3), 5.0, np.float32); bad[n // 2, 1] = np.nan
+                    sim.upload_state(bad)                                              # NaN
+                elif kind == 3:
+                    bad = np.full((n, 3), 5.0, np.float32); bad[0, 2] = 10.5
+                    sim.upload_state(bad)                                              # outside the box
+                else:
+                    sim.load_state(tmp_path / "no_such_file.sphsnap")
+        elif op == "step":
             sim.simulate(); ref.step(); steps += 1
         elif op == "timed":
             sim.simulateAndTime(t); ref.step(); steps += 1
