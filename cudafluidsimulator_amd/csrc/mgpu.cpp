@@ -657,9 +657,9 @@ int upload_common(sph_mgpu *m, const float *pos, const float *vel, int n) {
     const float hh = m->settings.h;
     for (int i = 0; i < n; ++i) {
         const float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
-        const int cx = (int)(x / hh), cy = (int)(y / hh), cz = (int)(z / hh);
-        if (!(x == x && y == y && z == z) || cx < 0 || cx >= m->D || cy < 0 || cy >= m->D || cz < 0 ||
-            cz >= m->D || x < 0.f || y < 0.f || z < 0.f)
+        // (range test before any float -> int conversion: that of a NaN / out-of-range value is undefined on the host)
+        const float qx = x / hh, qy = y / hh, qz = z / hh, Df = (float)m->D;
+        if (!(qx >= 0.f && qx < Df && qy >= 0.f && qy < Df && qz >= 0.f && qz < Df && x >= 0.f && y >= 0.f && z >= 0.f))
             return fail(m, SPH_EINVAL, "position outside the simulation box");
         uint32_t id = (uint32_t)i;
         float idbits;

@@ -684,12 +684,14 @@ int upload_common(sph_handle *h, const float *pos, const float *vel, int n) {
     int zmin = D, zmax = -1;
     for (int i = 0; i < n; ++i) {
         float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
-        int cx = (int)(x / hh), cy = (int)(y / hh), cz = (int)(z / hh);
+        // (the range test comes BEFORE the conversion: float -> int of a NaN or of a value beyond INT_MAX is
+        // undefined behaviour on the host -- found by the UBSan build under the fuzz tests' NaN upload)
+        const float qx = x / hh, qy = y / hh, qz = z / hh, Df = (float)D;
+        if (!(qx >= 0.f && qx < Df && qy >= 0.f && qy < Df && qz >= 0.f && qz < Df && x >= 0.f && y >= 0.f && z >= 0.f))
+            return fail(h, SPH_EINVAL, "position outside the simulation box");
+        const int cz = (int)qz;
         zmin = cz < zmin ? cz : zmin;
         zmax = cz > zmax ? cz : zmax;
-        if (!(x == x && y == y && z == z) || cx < 0 || cx >= D || cy < 0 || cy >= D ||
-            cz < 0 || cz >= D || x < 0.f || y < 0.f || z < 0.f)
-            return fail(h, SPH_EINVAL, "position outside the simulation box");
         uint32_t id = (uint32_t)i;
         float idbits;
         memcpy(&idbits, &id, 4);
@@ -1797,12 +1799,11 @@ int sph_load_state(sph_handle *h, const char *path) {
         seen[id] = 1;
         // the same box / NaN check as sph_upload_state: a corrupt file must not inject NaNs
         const float x = p4[i].x, y = p4[i].y, z = p4[i].z, hh = h->settings.h;
-        const int cx = (int)(x / hh), cy = (int)(y / hh), czc = (int)(z / hh);
-        const int D = h->P.D;
-        if (!(x == x && y == y && z == z) || cx < 0 || cx >= D || cy < 0 || cy >= D || czc < 0 || czc >= D ||
-            x < 0.f || y < 0.f || z < 0.f || !(v4[i].x == v4[i].x && v4[i].y == v4[i].y && v4[i].z == v4[i].z))
+        const float qx = x / hh, qy = y / hh, qz = z / hh, Df = (float)h->P.D; // (range test before any conversion)
+        if (!(qx >= 0.f && qx < Df && qy >= 0.f && qy < Df && qz >= 0.f && qz < Df && x >= 0.f && y >= 0.f && z >= 0.f) ||
+            !(v4[i].x == v4[i].x && v4[i].y == v4[i].y && v4[i].z == v4[i].z))
             return fail(h, SPH_EINVAL, "corrupt snapshot (position outside the simulation box / NaN)");
-        const int cz = (int)(p4[i].z / h->settings.h);
+        const int cz = (int)qz;
         zmin = cz < zmin ? cz : zmin;
         zmax = cz > zmax ? cz : zmax;
     }
