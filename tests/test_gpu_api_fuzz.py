@@ -142,3 +142,65 @@ def test_random_call_sequences_over_slabs_stay_on_the_oracle(seed, monkeypatch):
             assert_bit_equal(g[k], r[k], f"{tag}: {k}")
         assert_bit_equal(np.array(mg.getPosition()), r["pos"], f"{tag}: getPosition()")
     mg.close()
+
+
+def nasty_state(n, seed, fast_factor=30.0):
+    """Positions on the box faces and in the corner cells, on exact multiples of the cell size, coincident,
+    several hundred in one cell, a thin sheet; velocities up to 30 (three cells per step)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(0.1, 9.9, (n, 3)).astype(np.float32)
+    kind = rng.integers(0, 8, n)
+    face = kind == 0
+    pos[face] = np.where(rng.random((int(face.sum()), 3)) < 0.5, np.float32(0.1), np.float32(9.9))
+    onh = kind == 1                                              # exact multiples of h = 0.1f
+    pos[onh] = (rng.integers(1, 99, (int(onh.sum()), 3)).astype(np.float32) * np.float32(0.1))
+    same = kind == 2                                             # coincident (dist = 0: every term gated out)
+    pos[same] = np.float32(5.0)
+    crowd = kind == 3                                            # one crowded cell and its neighbours
+    pos[crowd] = (3.0 + 0.25 * rng.random((int(crowd.sum()), 3))).astype(np.float32)
+    sheet = kind == 4                                            # a sheet one cell thick
+    pos[sheet, 1] = (0.1 + 0.09 * rng.random(int(sheet.sum()))).astype(np.float32)
+    pos = np.clip(pos, np.float32(0.1), np.float32(9.9))
+    vel = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    fast = rng.random(n) < 0.02
+    vel[fast] *= np.float32(fast_factor)
+    return pos, vel
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_nasty_states_stay_on_the_oracle(seed):
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([3000, 12000, 40000]))
+    sweep = ["list", "list", "lds", "direct"][rng.integers(4)]
+    pos, vel = nasty_state(n, seed)
+    sim = sph.Simulator(sph.default_settings(n, False), sweep=sweep)
+    ref = O.OracleSim(n, False)
+    sim.upload_state(pos, vel)
+    ref.upload(pos, vel)
+    for k in range(4):
+        sim.simulate(); ref.step()
+        check(sim, ref, f"nasty seed {seed} ({sweep}, n {n}), step {k + 1}")
+    sim.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_nasty_states_over_slabs_stay_on_the_oracle(seed):
+    """The same states cut into z-slabs (fast particles cross one or two z-layers per step: migration through the
+    exchange; faces, coincident points and the crowded cell land on slab boundaries for some cuts)."""
+    from cudafluidsimulator_amd import mgpu as M
+    rng = np.random.default_rng(9500 + seed)
+    n = int(rng.choice([3000, 12000, 40000]))
+    world = int(rng.integers(2, 7))
+    transport = ["loopback", "streams"][rng.integers(2)]
+    pos, vel = nasty_state(n, 50 + seed, fast_factor=15.0)
+    mg = M.MultiGpuSimulator(sph.default_settings(n, False), world=world, transport=transport, recut_every=int(rng.choice([0, 2])))
+    ref = O.OracleSim(n, False)
+    mg.upload_state(pos, vel)
+    ref.upload(pos, vel)
+    for k in range(4):
+        mg.simulate(); ref.step()
+        g, r = mg.download_state(), ref.download()
+        for key in ("pos", "vel", "rho"):
+            assert_bit_equal(g[key], r[key], f"nasty seed {seed} ({world} slabs, {transport}, n {n}), step {k + 1}: {key}")
+    assert_bit_equal(np.array(mg.getPosition()), ref.download()["pos"], "getPosition()")
+    mg.close()
