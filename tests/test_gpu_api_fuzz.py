@@ -168,8 +168,10 @@ def nasty_state(n, seed, fast_factor=30.0):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_nasty_states_stay_on_the_oracle(seed):
+def test_nasty_states_stay_on_the_oracle(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
+    if seed % 3 == 0:  # a hit-stream pool far too small: some waves record, the rest go through k_force_fallback
+        monkeypatch.setenv("SPH_MASK_POOL_WORDS", str(int(rng.choice([4096, 60000, 400000]))))
     n = int(rng.choice([3000, 12000, 40000]))
     sweep = ["list", "list", "lds", "direct"][rng.integers(4)]
     pos, vel = nasty_state(n, seed)
@@ -184,11 +186,13 @@ def test_nasty_states_stay_on_the_oracle(seed):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_nasty_states_over_slabs_stay_on_the_oracle(seed):
+def test_nasty_states_over_slabs_stay_on_the_oracle(seed, monkeypatch):
     """The same states cut into z-slabs (fast particles cross one or two z-layers per step: migration through the
     exchange; faces, coincident points and the crowded cell land on slab boundaries for some cuts)."""
     from cudafluidsimulator_amd import mgpu as M
     rng = np.random.default_rng(9500 + seed)
+    if seed % 2 == 0:  # (per slab: interior and boundary launches both walk the list of waves without a stream)
+        monkeypatch.setenv("SPH_MASK_POOL_WORDS", str(int(rng.choice([4096, 60000]))))
     n = int(rng.choice([3000, 12000, 40000]))
     world = int(rng.integers(2, 7))
     transport = ["loopback", "streams"][rng.integers(2)]
