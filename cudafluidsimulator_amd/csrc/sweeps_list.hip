@@ -391,7 +391,11 @@ void k_density_mask_lds(DevParams P, SweepArgs A) {
 #pragma unroll
                         for (int u = 0; u < SW_UNROLL; ++u) {
                             const float4 *p = (k + u < len) ? cur + k : sent;
+#if defined(SL_DBG_ONE_READ) // (perf-only: one LDS read per trip instead of four -- is the loop bound by LDS traffic?)
+                            pj[u] = u == 0 ? p[0] : make_float4(pj[0].x + (float)u, pj[0].y, pj[0].z, 0.f);
+#else
                             pj[u] = p[u];
+#endif
                         }
                         trip(pj);
                     }
